@@ -1,0 +1,190 @@
+"""Deterministic synthetic weights and patches for the modelv2 hot path.
+
+The reference's trained checkpoints and its BigEarthNet patches are absent
+(/root/reference/.MISSING_LARGE_BLOBS), so parity and throughput are defined
+on synthetic tensors.  Everything here is a pure integer hash -> exact float32
+(24-bit mantissa fractions), so this container, the GPU box and any rank of a
+multi-GPU job produce bit-identical tensors without shipping data.
+
+State-dict key set and shapes follow the reference modules
+(code/modelv2/layers.py:46-152, code/modelv2/distributions.py:33-37,
+code/modelv2/model.py:12-25).
+"""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+
+REPARAM_OFFSET = 2.0 ** -18          # layers.py:8
+PATCH_SEED = 20250912
+WEIGHT_SEED = 1
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    """splitmix64 finaliser on a uint64 array (wrap-around arithmetic)."""
+    with np.errstate(over="ignore"):
+        x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        x = ((x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        x = ((x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        x = x ^ (x >> np.uint64(31))
+    return x
+
+
+def hash_uniform(n: int, seed: int, stream: int, offset: int = 0) -> np.ndarray:
+    """n float32 values, uniform on [0,1) with 24-bit resolution.
+
+    value[i] = top 24 bits of splitmix64(splitmix64(seed, stream) + offset + i).
+    """
+    key = _splitmix64(np.array([(seed << 32) ^ (stream & 0xFFFFFFFF)],
+                               dtype=np.uint64))[0]
+    with np.errstate(over="ignore"):
+        idx = (np.arange(offset, offset + n, dtype=np.uint64) + key) & _M64
+    h = _splitmix64(idx)
+    return ((h >> np.uint64(40)).astype(np.float32)
+            * np.float32(2.0 ** -24)).astype(np.float32)
+
+
+def _stream_id(name: str) -> int:
+    return zlib.crc32(name.encode()) & 0xFFFFFFFF
+
+
+def state_dict_spec(N: int = 128, M: int = 192, in_ch: int = 3):
+    """[(key, shape, kind, fan_in)] in the reference's state_dict order."""
+    spec = []
+
+    def conv(prefix, cout, cin, k):
+        spec.append((prefix + ".weight", (cout, cin, k, k), "w", cin * k * k))
+        spec.append((prefix + ".bias", (cout,), "b", cin * k * k))
+
+    def convT(prefix, cin, cout, k):
+        # nn.ConvTranspose2d weight is [Cin, Cout, kH, kW]; torch computes
+        # fan_in from dim 1 (= Cout) * k * k for the default init.
+        spec.append((prefix + ".weight", (cin, cout, k, k), "w", cout * k * k))
+        spec.append((prefix + ".bias", (cout,), "b", cout * k * k))
+
+    def gdn(prefix, c):
+        spec.append((prefix + ".beta", (c,), "beta", 0))
+        spec.append((prefix + ".gamma", (c, c), "gamma_dead", 0))
+        spec.append((prefix + ".gamma_conv.weight", (c, 1, 1, 1), "gamma", 0))
+
+    # g_a  (layers.py:49-73)
+    ga = [(in_ch, N, 3), (N, N, 5), (N, N, 3), (N, N, 5), (N, N, 3), (N, N, 5),
+          (N, N, 3), (N, M, 5)]
+    for i, (ci, co, k) in enumerate(ga):
+        conv(f"g_a.g_a.{2 * i}", co, ci, k)
+        if i < 7:
+            gdn(f"g_a.g_a.{2 * i + 1}", N)
+    # g_s  (layers.py:81-98)
+    gs = [("T", M, N), ("c", N, N), ("T", N, N), ("c", N, N), ("T", N, N),
+          ("c", N, N), ("T", N, in_ch)]
+    for i, (kind, ci, co) in enumerate(gs):
+        if kind == "T":
+            convT(f"g_s.g_s.{2 * i}", ci, co, 5)
+        else:
+            conv(f"g_s.g_s.{2 * i}", co, ci, 3)
+        if i < 6:
+            gdn(f"g_s.g_s.{2 * i + 1}", N)
+    # h_a  (layers.py:107-113)
+    for idx, (ci, co, k) in zip((0, 2, 4, 6),
+                                [(M, N, 3), (N, N, 3), (N, N, 5), (N, N, 5)]):
+        conv(f"h_a.h_a.{idx}", co, ci, k)
+    # h_s  (layers.py:122-139), non-spatial heads
+    convT("h_s.h_s.0", N, N, 5)
+    convT("h_s.h_s.2", N, N, 5)
+    for head in ("mlp_sigma", "mlp_nu"):
+        conv(f"h_s.{head}.0", N, N, 1)
+        conv(f"h_s.{head}.2", M, N, 1)
+    spec.append(("z_prior.log_sigma", (N,), "logsig", 0))
+    return spec
+
+
+# Scales that make the random-init network non-degenerate (SURVEY.md §8c:
+# default init gives |y| < 0.06 so round(y) == 0 everywhere).
+_WEIGHT_GAIN = {
+    "g_a.g_a.14.weight": 150.0,
+    "h_a.h_a.6.weight": 40.0,
+}
+_BIAS_SHIFT = {
+    "h_s.mlp_nu.2.bias": 1.5,
+    "h_s.mlp_sigma.2.bias": 1.0,
+    "g_s.g_s.12.bias": 0.5,
+}
+
+
+def make_state_dict(seed: int = WEIGHT_SEED, N: int = 128, M: int = 192,
+                    in_ch: int = 3) -> "OrderedDict[str, np.ndarray]":
+    """Synthetic float32 state_dict with the reference's 90 keys."""
+    sd = OrderedDict()
+    for key, shape, kind, fan_in in state_dict_spec(N, M, in_ch):
+        n = int(np.prod(shape))
+        u = hash_uniform(n, seed, _stream_id(key))
+        if kind in ("w", "b"):
+            bound = np.float32(1.0 / np.sqrt(fan_in))
+            v = (u * np.float32(2.0) - np.float32(1.0)) * bound
+            if kind == "w":
+                v = v * np.float32(_WEIGHT_GAIN.get(key, 1.0))
+            else:
+                v = v + np.float32(_BIAS_SHIFT.get(key, 0.0))
+                if key == "h_s.mlp_nu.2.bias":
+                    # drive a few channels to both nu clamps (min_nu, max_nu)
+                    v[0::37] = np.float32(-3.0)
+                    v[5::41] = np.float32(6.0)
+        elif kind == "beta":
+            beta_eff = np.float32(0.5) + u            # [0.5, 1.5)
+            v = np.sqrt(beta_eff + np.float32(REPARAM_OFFSET))
+        elif kind == "gamma":
+            gamma_eff = np.float32(0.02) + u * np.float32(0.28)
+            v = np.sqrt(gamma_eff + np.float32(REPARAM_OFFSET))
+        elif kind == "gamma_dead":
+            # never read in forward (layers.py:13 vs :19-27); keep the
+            # reference's init so load_state_dict(strict=True) is satisfied
+            c = shape[0]
+            v = np.sqrt(np.eye(c, dtype=np.float32) * np.float32(0.1)
+                        + np.float32(REPARAM_OFFSET)).reshape(-1)
+        elif kind == "logsig":
+            v = (u - np.float32(0.5)) * np.float32(2.0) + np.float32(1.0)
+        else:  # pragma: no cover
+            raise AssertionError(kind)
+        sd[key] = np.ascontiguousarray(v.astype(np.float32).reshape(shape))
+    return sd
+
+
+def make_patches(first_index: int, count: int, H: int = 256, W: int = 256,
+                 C: int = 3, seed: int = PATCH_SEED) -> np.ndarray:
+    """count patches [count,C,H,W] float32 in [0,1], stream = global index.
+
+    Three octaves of bilinearly up-sampled hash noise plus a little white
+    noise, so the patch has image-like low-frequency structure; any shard can
+    regenerate exactly its slice of the global batch.
+    """
+    out = np.empty((count, C, H, W), dtype=np.float32)
+    for i in range(count):
+        g = first_index + i
+        img = np.zeros((C, H, W), dtype=np.float32)
+        amp_total = np.float32(0.0)
+        for octave, (cells, amp) in enumerate(((4, 0.5), (16, 0.3), (64, 0.15))):
+            gh, gw = cells + 1, cells + 1
+            grid = hash_uniform(C * gh * gw, seed, g * 8 + octave).reshape(C, gh, gw)
+            ys = (np.arange(H, dtype=np.float32) + np.float32(0.5)) * np.float32(cells / H)
+            xs = (np.arange(W, dtype=np.float32) + np.float32(0.5)) * np.float32(cells / W)
+            y0 = np.minimum(ys.astype(np.int64), cells - 1)
+            x0 = np.minimum(xs.astype(np.int64), cells - 1)
+            fy = (ys - y0.astype(np.float32))[None, :, None]
+            fx = (xs - x0.astype(np.float32))[None, None, :]
+            g00 = grid[:, y0][:, :, x0]
+            g01 = grid[:, y0][:, :, x0 + 1]
+            g10 = grid[:, y0 + 1][:, :, x0]
+            g11 = grid[:, y0 + 1][:, :, x0 + 1]
+            layer = (g00 * (1 - fy) * (1 - fx) + g01 * (1 - fy) * fx
+                     + g10 * fy * (1 - fx) + g11 * fy * fx)
+            img += np.float32(amp) * layer.astype(np.float32)
+            amp_total += np.float32(amp)
+        white = hash_uniform(C * H * W, seed, g * 8 + 7).reshape(C, H, W)
+        img = img + np.float32(0.05) * white
+        img = img / (amp_total + np.float32(0.05))
+        out[i] = np.clip(img, 0.0, 1.0).astype(np.float32)
+    return out
