@@ -1,0 +1,70 @@
+"""Builds libdsic_hip.so (gfx950) in-tree with hipcc.
+
+    python domain-specific-image-compression_amd/build.py [--force]
+
+Objects go to csrc/_obj/, the shared library next to this file.  hipcc
+cross-compiles without a GPU, so this also runs in the GPU-less build
+container; the built .so travels to the GPU box with the repository snapshot.
+"""
+from __future__ import annotations
+
+import concurrent.futures
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libdsic_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+# -ffp-contract=off: the fp64 table math and the GDN epilogue must not be fused
+# differently from their CPU restatements.
+FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-ffp-contract=off",
+         "-Wall", "-Wno-unused-function", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
+
+
+def _sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
+
+
+def _deps_mtime():
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    return max([os.path.getmtime(h) for h in hdrs] + [os.path.getmtime(__file__)])
+
+
+def _compile(src, obj):
+    cmd = [HIPCC, *FLAGS, "-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    return r.stderr
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    hdr_m = _deps_mtime()
+    jobs, objs = [], []
+    for src in _sources():
+        obj = os.path.join(OBJ, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_m):
+            jobs.append((src, obj))
+    if jobs:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            for (src, _), warn in zip(jobs, ex.map(lambda j: _compile(*j), jobs)):
+                if verbose or warn.strip():
+                    print(f"[dsic build] {os.path.basename(src)}\n{warn}", file=sys.stderr)
+    if jobs or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,177 @@
+// Weight re-layout and NCHW<->NHWC helpers (run once per checkpoint load or at
+// the NCHW boundary of the reference API; none of them is on the timed path
+// except image_to_nhwc8 and the small latent transposes).
+#include "common.h"
+
+namespace dsic {
+
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ dst,
+                                        int Cout, int Cin, int k, int Cin8, int CoutP,
+                                        int64_t total) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int j = i & 7;
+  int64_t r = i >> 3;
+  const int n = r % CoutP;
+  r /= CoutP;
+  const int c8 = r % Cin8;
+  const int t = r / Cin8;
+  const int c = c8 * 8 + j;
+  const int ky = t / k, kx = t % k;
+  float v = 0.f;
+  if (n < Cout && c < Cin) v = w[(((int64_t)n * Cin + c) * k + ky) * k + kx];
+  dst[i] = v;
+}
+
+// phase p = py*2+px owns taps [base[p], base[p]+(3-py)(3-px)); local tap
+// (ty,tx) reads input (oy-1+ty+py, ox-1+tx+px) and kernel element
+// ky = py+4-2(ty+py), kx = px+4-2(tx+px)  (from oy = 2*iy - 2 + ky).
+__global__ void pack_convT_weight_kernel(const float* __restrict__ w, float* __restrict__ dst,
+                                         int Cin, int Cout, int Cin8, int CoutP, int64_t total) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int j = i & 7;
+  int64_t r = i >> 3;
+  const int n = r % CoutP;
+  r /= CoutP;
+  const int c8 = r % Cin8;
+  const int T = r / Cin8;  // 0..24
+  const int phase = T < 9 ? 0 : (T < 15 ? 1 : (T < 21 ? 2 : 3));
+  const int base = phase == 0 ? 0 : (phase == 1 ? 9 : (phase == 2 ? 15 : 21));
+  const int py = phase >> 1, px = phase & 1;
+  const int ntx = 3 - px;
+  const int tl = T - base;
+  const int ty = tl / ntx, tx = tl % ntx;
+  const int ky = py + 4 - 2 * (ty + py), kx = px + 4 - 2 * (tx + px);
+  const int c = c8 * 8 + j;
+  float v = 0.f;
+  if (n < Cout && c < Cin) v = w[(((int64_t)c * Cout + n) * 5 + ky) * 5 + kx];
+  dst[i] = v;
+}
+
+__global__ void pack_convT_image_weight_kernel(const float* __restrict__ w,
+                                               float* __restrict__ dst, int Cin, int Cimg,
+                                               int Cin8, int64_t total) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int j = i & 7;
+  int64_t r = i >> 3;
+  const int n = r % 32;
+  r /= 32;
+  const int c8 = r % Cin8;
+  const int t = r / Cin8;  // 0..8
+  const int wr = t / 3, wc = t % 3;
+  const int c = c8 * 8 + j;
+  float v = 0.f;
+  if (n < 4 * Cimg && c < Cin) {
+    const int ci = n % Cimg, ph = n / Cimg;
+    const int py = ph >> 1, px = ph & 1;
+    if (wr >= py && wc >= px) {
+      const int ky = py + 4 - 2 * wr, kx = px + 4 - 2 * wc;
+      v = w[(((int64_t)c * Cimg + ci) * 5 + ky) * 5 + kx];
+    }
+  }
+  dst[i] = v;
+}
+
+__global__ void image_to_nhwc8_kernel(const float* __restrict__ x, float* __restrict__ dst, int C,
+                                      int HW, int64_t total) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B*HW pixels
+  if (i >= total) return;
+  const int64_t b = i / HW;
+  const int p = i % HW;
+  float v[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) v[c] = c < C ? x[(b * C + c) * HW + p] : 0.f;
+  float4* o = (float4*)(dst + i * 8);
+  o[0] = make_float4(v[0], v[1], v[2], v[3]);
+  o[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// 32x32 tile transpose through LDS: src viewed as [R][Cc] per batch -> [Cc][R].
+__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R,
+                                 int Cc) {
+  __shared__ float tile[32][33];
+  const int64_t b = blockIdx.z;
+  const float* s = src + b * (int64_t)R * Cc;
+  float* d = dst + b * (int64_t)R * Cc;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    if (r < R && c < Cc) tile[i][threadIdx.x] = s[(int64_t)r * Cc + c];
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + threadIdx.x;
+    if (r < R && c < Cc) d[(int64_t)c * R + r] = tile[threadIdx.x][i];
+  }
+}
+
+static int transpose_launch(const float* src, float* dst, int B, int R, int Cc, hipStream_t st) {
+  dim3 grid(ceil_div(Cc, 32), ceil_div(R, 32), B), block(32, 8);
+  hipLaunchKernelGGL(transpose_kernel, grid, block, 0, st, src, dst, R, Cc);
+  return check_launch("transpose");
+}
+
+}  // namespace dsic
+
+using namespace dsic;
+
+extern "C" int64_t dsic_packed_conv_weight_floats(int Cout, int Cin, int k) {
+  return (int64_t)k * k * (round_up(Cin, 8) / 8) * round_up(Cout, 32) * 8;
+}
+
+extern "C" int dsic_pack_conv_weight(const float* w, float* dst, int Cout, int Cin, int k,
+                                     void* stream) {
+  DSIC_REQUIRE(w && dst, "pack_conv_weight: null pointer");
+  DSIC_REQUIRE(Cout > 0 && Cin > 0 && (k == 1 || k == 3 || k == 5), "pack_conv_weight: bad shape");
+  const int Cin8 = round_up(Cin, 8) / 8, CoutP = round_up(Cout, 32);
+  const int64_t total = dsic_packed_conv_weight_floats(Cout, Cin, k);
+  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, w, dst, Cout, Cin, k, Cin8, CoutP, total);
+  return check_launch("pack_conv_weight");
+}
+
+extern "C" int dsic_pack_convT_weight(const float* w, float* dst, int Cin, int Cout,
+                                      void* stream) {
+  DSIC_REQUIRE(w && dst, "pack_convT_weight: null pointer");
+  DSIC_REQUIRE(Cout > 0 && Cin > 0 && Cin % 8 == 0, "pack_convT_weight: Cin must be a multiple of 8");
+  const int Cin8 = Cin / 8, CoutP = round_up(Cout, 32);
+  const int64_t total = (int64_t)25 * Cin8 * CoutP * 8;
+  hipLaunchKernelGGL(pack_convT_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, w, dst, Cin, Cout, Cin8, CoutP, total);
+  return check_launch("pack_convT_weight");
+}
+
+extern "C" int dsic_pack_convT_image_weight(const float* w, float* dst, int Cin, int Cimg,
+                                            void* stream) {
+  DSIC_REQUIRE(w && dst, "pack_convT_image_weight: null pointer");
+  DSIC_REQUIRE(Cin > 0 && Cin % 8 == 0 && Cimg >= 1 && Cimg <= 8, "pack_convT_image_weight: bad shape");
+  const int Cin8 = Cin / 8;
+  const int64_t total = (int64_t)9 * Cin8 * 32 * 8;
+  hipLaunchKernelGGL(pack_convT_image_weight_kernel, dim3((unsigned)((total + 255) / 256)),
+                     dim3(256), 0, (hipStream_t)stream, w, dst, Cin, Cimg, Cin8, total);
+  return check_launch("pack_convT_image_weight");
+}
+
+extern "C" int dsic_image_to_nhwc8(const float* x, float* dst, int B, int C, int H, int W,
+                                   void* stream) {
+  DSIC_REQUIRE(x && dst, "image_to_nhwc8: null pointer");
+  DSIC_REQUIRE(B > 0 && C >= 1 && C <= 8 && H > 0 && W > 0, "image_to_nhwc8: bad shape");
+  const int64_t total = (int64_t)B * H * W;
+  hipLaunchKernelGGL(image_to_nhwc8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, dst, C, H * W, total);
+  return check_launch("image_to_nhwc8");
+}
+
+extern "C" int dsic_nhwc_to_nchw(const float* src, float* dst, int B, int H, int W, int C,
+                                 void* stream) {
+  DSIC_REQUIRE(src && dst && B > 0 && H > 0 && W > 0 && C > 0, "nhwc_to_nchw: bad argument");
+  return transpose_launch(src, dst, B, H * W, C, (hipStream_t)stream);
+}
+
+extern "C" int dsic_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W,
+                                 void* stream) {
+  DSIC_REQUIRE(src && dst && B > 0 && H > 0 && W > 0 && C > 0, "nchw_to_nhwc: bad argument");
+  return transpose_launch(src, dst, B, C, H * W, (hipStream_t)stream);
+}

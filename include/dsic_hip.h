@@ -1,0 +1,103 @@
+/* dsic_hip.h — C ABI of libdsic_hip.so, the MI355X (gfx950) hot path of the
+ * modelv2 Student-t hyperprior codec.
+ *
+ * The reference (Dimitrinov74/Domain-Specific-Image-Compression) has no FFI
+ * layer: its seam is the Python module API of code/modelv2.  Each entry point
+ * below replaces the torch op sequence of the cited reference lines; the
+ * ctypes binding a maintainer would add is shown in INTEGRATION.md and lives
+ * in domain-specific-image-compression_amd/lib.py.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - the library allocates nothing and keeps no state; callers own all
+ *     buffers including workspaces;
+ *   - activations are NHWC float32 with a channel count that is a multiple
+ *     of 8; image tensors at the boundary are NCHW float32 like the
+ *     reference's (eval_selfcontained.py:58-59);
+ *   - return value: 0 = ok, DSIC_EINVAL = bad argument, DSIC_EHIP = a HIP
+ *     runtime error (hipGetLastError text via dsic_last_error()).
+ */
+#ifndef DSIC_HIP_H
+#define DSIC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSIC_OK 0
+#define DSIC_EINVAL 1
+#define DSIC_EHIP 2
+
+/* activation fused into the conv epilogue */
+#define DSIC_ACT_NONE 0
+#define DSIC_ACT_GDN 1   /* x / sqrt(beta + gamma*x^2)   layers.py:19-27 */
+#define DSIC_ACT_IGDN 2  /* x * sqrt(beta + gamma*x^2)   layers.py:24-25 */
+#define DSIC_ACT_RELU 3  /* nn.ReLU                      layers.py:108-111 */
+
+const char* dsic_last_error(void);
+int dsic_abi_version(void);
+
+/* ---- weight re-layout (once per checkpoint load) ------------------------ */
+
+/* nn.Conv2d weight [Cout,Cin,k,k] (layers.py:29-31) -> packed
+ * [k*k][CinP/8][CoutP][8], CinP = ceil8(Cin), CoutP = ceil32(Cout), zero
+ * padded.  dst must hold dsic_packed_conv_weight_floats() floats. */
+int64_t dsic_packed_conv_weight_floats(int Cout, int Cin, int k);
+int dsic_pack_conv_weight(const float* w_oihw, float* dst, int Cout, int Cin,
+                          int k, void* stream);
+
+/* nn.ConvTranspose2d(Cin,Cout,5,2,2,output_padding=1) weight [Cin,Cout,5,5]
+ * (layers.py:83,89,93,123,124) -> the four sub-pixel phase kernels
+ * (3x3,3x2,2x3,2x2 taps = all 25 taps) packed [25][Cin/8][CoutP][8]. */
+int dsic_pack_convT_weight(const float* w_iohw, float* dst, int Cin, int Cout,
+                           void* stream);
+
+/* Last synthesis layer ConvTranspose2d(Cin,Cimg,5,2,2,1) (layers.py:97):
+ * the four phases become the 4*Cimg output columns of ONE 3x3 stride-1
+ * contraction over the input grid; packed [9][Cin/8][32][8]. */
+int dsic_pack_convT_image_weight(const float* w_iohw, float* dst, int Cin,
+                                 int Cimg, void* stream);
+
+/* ---- layout helpers ------------------------------------------------------ */
+
+/* NCHW image [B,C,H,W] -> NHWC with C padded to 8 (zeros). */
+int dsic_image_to_nhwc8(const float* x_nchw, float* dst_nhwc8, int B, int C,
+                        int H, int W, void* stream);
+/* NHWC [B,H,W,C] -> NCHW [B,C,H,W] */
+int dsic_nhwc_to_nchw(const float* src, float* dst, int B, int H, int W, int C,
+                      void* stream);
+/* NCHW [B,C,H,W] -> NHWC [B,H,W,C] */
+int dsic_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W,
+                      void* stream);
+
+/* ---- convolutions (fp32 MFMA implicit GEMM, fused bias + activation) ----- */
+
+/* conv() + optional GDN/ReLU: nn.Conv2d(Cin,Cout,k,stride,padding=(k-1)/2)
+ * (layers.py:29-31, 51-72, 86-94, 108-112).  k in {3,5}; (k,stride) in
+ * {(3,1),(5,2)}.  in: NHWC [B,H,W,CinP]; out: NHWC [B,Ho,Wo,Cout],
+ * Ho = ceil(H/stride).  beta/gamma are the EFFECTIVE per-channel values
+ * (param^2 - 2^-18, layers.py:20-21); ignored unless act is GDN/IGDN. */
+int dsic_conv2d_nhwc(const float* in, const float* w_packed, const float* bias,
+                     const float* beta, const float* gamma, float* out, int B,
+                     int H, int W, int CinP, int Cout, int k, int stride,
+                     int act, void* stream);
+
+/* ConvTranspose2d(Cin,Cout,5,2,2,output_padding=1) + optional IGDN/ReLU.
+ * in NHWC [B,H,W,Cin] -> out NHWC [B,2H,2W,Cout]. */
+int dsic_conv_transpose2d_nhwc(const float* in, const float* w_packed,
+                               const float* bias, const float* beta,
+                               const float* gamma, float* out, int B, int H,
+                               int W, int Cin, int Cout, int act, void* stream);
+
+/* Last synthesis layer: in NHWC [B,H,W,Cin] -> x_hat NCHW [B,Cimg,2H,2W]. */
+int dsic_conv_transpose2d_image(const float* in, const float* w_packed,
+                                const float* bias, float* out_nchw, int B,
+                                int H, int W, int Cin, int Cimg, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSIC_HIP_H */

@@ -1,0 +1,170 @@
+"""HIP conv kernels (through the C ABI) vs the oracle ops on the same inputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_model as O
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from dsic_amd import ops as _ops
+    return _ops
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _pad8(x_nhwc):
+    c = x_nhwc.shape[-1]
+    if c % 8 == 0:
+        return x_nhwc
+    return torch.nn.functional.pad(x_nhwc, (0, 8 - c % 8))
+
+
+def _tol(ref, K):
+    return 2e-6 * float(ref.abs().max()) * max(1.0, K ** 0.5 / 8) + 1e-6
+
+
+def test_layout_roundtrip(ops):
+    x = _rand((3, 5, 7, 11), 0).cuda()
+    y = ops.nchw_to_nhwc(x)
+    assert torch.equal(y, x.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(ops.nhwc_to_nchw(y), x)
+    img = _rand((2, 3, 9, 13), 1).cuda()
+    p = ops.image_to_nhwc8(img)
+    assert torch.equal(p[..., :3], img.permute(0, 2, 3, 1))
+    assert float(p[..., 3:].abs().max()) == 0.0
+
+
+def test_units_against_reference_fixtures(ops):
+    """Reference conv()/ConvTranspose2d outputs recorded by make_golden.py."""
+    u = np.load(os.path.join(GOLDEN, "units.npz"))
+    for tag in sorted({k.split("/")[0] for k in u.files if k.startswith("conv_k")}):
+        k = int(tag.split("_")[1][1])
+        s = int(tag.split("_")[1][3])
+        if k == 1:
+            continue
+        w = torch.from_numpy(u[tag + "/w"]).cuda()
+        b = torch.from_numpy(u[tag + "/b"]).cuda()
+        x = torch.from_numpy(u[tag + "/x"]).cuda()
+        y = ops.conv2d_nhwc(_nhwc(x), ops.pack_conv_weight(w), b, w.shape[0], k, s)
+        ref = torch.from_numpy(u[tag + "/y"])
+        np.testing.assert_allclose(ops.nhwc_to_nchw(y).cpu().numpy(), ref.numpy(), atol=_tol(ref, 200))
+    for tag in sorted({k.split("/")[0] for k in u.files if k.startswith("convT")}):
+        w = torch.from_numpy(u[tag + "/w"]).cuda()
+        b = torch.from_numpy(u[tag + "/b"]).cuda()
+        x = torch.from_numpy(u[tag + "/x"]).cuda()
+        ref = torch.from_numpy(u[tag + "/y"])
+        cout = w.shape[1]
+        if cout % 8 == 0:
+            y = ops.nhwc_to_nchw(ops.conv_transpose2d_nhwc(_nhwc(x), ops.pack_convT_weight(w), b, cout))
+        else:
+            y = ops.conv_transpose2d_image(_nhwc(x), ops.pack_convT_image_weight(w), b, cout)
+        np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), atol=_tol(ref, 200))
+
+
+CONV_CASES = [
+    # B, Cin, Cout, H, W, k, s, act
+    (1, 3, 128, 32, 48, 3, 1, "gdn"),        # g_a.0 shape family (Cin padded to 8)
+    (2, 128, 128, 40, 24, 5, 2, "gdn"),      # g_a.2/6/10
+    (1, 128, 128, 19, 37, 3, 1, "gdn"),      # odd sizes, tile borders
+    (1, 128, 128, 17, 33, 5, 2, "none"),
+    (3, 128, 192, 10, 14, 5, 2, "none"),     # g_a.14 (two column tiles per wave)
+    (3, 192, 128, 6, 8, 3, 1, "relu"),       # h_a.0, 8x8x2 tile
+    (5, 128, 128, 6, 8, 5, 2, "relu"),       # h_a.4 -> 3x4 grid, 4x4x8 tile, ragged batch
+    (9, 128, 128, 3, 4, 5, 2, "none"),       # h_a.6
+    (2, 128, 128, 16, 16, 3, 1, "igdn"),     # g_s conv
+    (1, 4, 128, 16, 24, 3, 1, "gdn"),        # 4-band first layer
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,k,s,act", CONV_CASES)
+def test_conv2d_vs_oracle(ops, B, Cin, Cout, H, W, k, s, act):
+    x = _rand((B, Cin, H, W), 1, 2.0)
+    w = _rand((Cout, Cin, k, k), 2, (Cin * k * k) ** -0.5 * 2)
+    b = _rand((Cout,), 3, 0.5)
+    beta_p = torch.sqrt(0.5 + torch.rand(Cout, generator=torch.Generator().manual_seed(4)) + 2 ** -18)
+    gam_p = torch.sqrt(0.02 + 0.28 * torch.rand(Cout, generator=torch.Generator().manual_seed(5)) + 2 ** -18)
+    sd = {"p.weight": w, "p.bias": b}
+    ref = O._conv(sd, "p", x, s)
+    code = {"none": ops.ACT_NONE, "gdn": ops.ACT_GDN, "igdn": ops.ACT_IGDN, "relu": ops.ACT_RELU}[act]
+    if act in ("gdn", "igdn"):
+        ref = O.gdn(ref, beta_p, gam_p.view(-1, 1, 1, 1), act == "igdn")
+    elif act == "relu":
+        ref = torch.relu(ref)
+    beta = (beta_p ** 2 - 2 ** -18).cuda()
+    gamma = (gam_p ** 2 - 2 ** -18).cuda()
+    y = ops.conv2d_nhwc(_pad8(_nhwc(x)).cuda(), ops.pack_conv_weight(w.cuda()), b.cuda(), Cout, k, s,
+                        code, beta, gamma)
+    got = ops.nhwc_to_nchw(y).cpu()
+    assert got.shape == ref.shape
+    err = float((got - ref).abs().max())
+    assert err <= _tol(ref, Cin * k * k) * 4, (err, float(ref.abs().max()))
+
+
+CONVT_CASES = [
+    (2, 192, 128, 5, 7, "igdn"),     # g_s.0
+    (1, 128, 128, 16, 24, "igdn"),   # g_s.4/8
+    (1, 128, 128, 9, 17, "relu"),    # h_s, odd grid
+    (9, 128, 128, 2, 3, "relu"),     # h_s.0 on tiny z, ragged 4x4x8 tile
+    (3, 128, 128, 8, 6, "none"),
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,act", CONVT_CASES)
+def test_conv_transpose_vs_oracle(ops, B, Cin, Cout, H, W, act):
+    x = _rand((B, Cin, H, W), 11, 2.0)
+    w = _rand((Cin, Cout, 5, 5), 12, (Cin * 6.25) ** -0.5 * 2)
+    b = _rand((Cout,), 13, 0.5)
+    beta_p = torch.sqrt(0.5 + torch.rand(Cout, generator=torch.Generator().manual_seed(4)) + 2 ** -18)
+    gam_p = torch.sqrt(0.02 + 0.28 * torch.rand(Cout, generator=torch.Generator().manual_seed(5)) + 2 ** -18)
+    ref = O._convT({"p.weight": w, "p.bias": b}, "p", x)
+    code = {"none": ops.ACT_NONE, "igdn": ops.ACT_IGDN, "relu": ops.ACT_RELU}[act]
+    if act == "igdn":
+        ref = O.gdn(ref, beta_p, gam_p.view(-1, 1, 1, 1), True)
+    elif act == "relu":
+        ref = torch.relu(ref)
+    y = ops.conv_transpose2d_nhwc(_nhwc(x).cuda(), ops.pack_convT_weight(w.cuda()), b.cuda(), Cout, code,
+                                  (beta_p ** 2 - 2 ** -18).cuda(), (gam_p ** 2 - 2 ** -18).cuda())
+    got = ops.nhwc_to_nchw(y).cpu()
+    assert got.shape == ref.shape
+    err = float((got - ref).abs().max())
+    assert err <= _tol(ref, Cin * 9) * 4, (err, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("B,Cin,Cimg,H,W", [(2, 128, 3, 16, 24), (1, 128, 4, 9, 5), (9, 128, 3, 3, 4)])
+def test_conv_transpose_image_vs_oracle(ops, B, Cin, Cimg, H, W):
+    x = _rand((B, Cin, H, W), 21, 2.0)
+    w = _rand((Cin, Cimg, 5, 5), 22, (Cin * 6.25) ** -0.5 * 2)
+    b = _rand((Cimg,), 23, 0.5)
+    ref = O._convT({"p.weight": w, "p.bias": b}, "p", x)
+    got = ops.conv_transpose2d_image(_nhwc(x).cuda(), ops.pack_convT_image_weight(w.cuda()), b.cuda(), Cimg).cpu()
+    assert got.shape == ref.shape
+    err = float((got - ref).abs().max())
+    assert err <= _tol(ref, Cin * 9) * 4, (err, float(ref.abs().max()))
+
+
+def test_bad_arguments_raise(ops):
+    x = torch.zeros((1, 4, 4, 8), device="cuda")
+    w = torch.zeros(9 * 32 * 8, device="cuda")
+    b = torch.zeros(8, device="cuda")
+    with pytest.raises(ValueError):
+        ops.conv2d_nhwc(x, w, b, 8, 3, 2)          # (k,stride) not supported
+    with pytest.raises(ValueError):
+        ops.conv2d_nhwc(x, w, b, 8, 3, 1, ops.ACT_GDN)   # GDN without beta/gamma
+    with pytest.raises(RuntimeError):
+        ops.conv2d_nhwc(x.cpu(), w, b, 8, 3, 1)    # no CPU fallback
