@@ -1,0 +1,298 @@
+"""Host-side mirror of the reference's transform modules (code/modelv2/layers.py).
+
+Same class names, constructor arguments, parameter names (so the reference's
+state_dict loads with strict=True) and NCHW tensor contract; the compute is the
+HIP library.  Every transform also has a `forward_nhwc` used by
+CompressionModel.forward to chain layers without leaving NHWC.
+
+Inference only: parameters are plain tensors for the kernels, no autograd.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class _GammaConv(nn.Module):
+    """Holder for `gamma_conv.weight` [C,1,1,1] (layers.py:15-17)."""
+
+    def __init__(self, channels, init):
+        super().__init__()
+        self.weight = nn.Parameter(init.view(channels, 1, 1, 1).clone(), requires_grad=False)
+
+
+class GDN(nn.Module):
+    """Diagonal GDN / IGDN (layers.py:6-27): x / sqrt(beta_c + gamma_c x^2)."""
+
+    def __init__(self, channels, inverse=False, beta_min=1e-6, gamma_init=0.1,
+                 reparam_offset=2 ** -18):
+        super().__init__()
+        self.inverse = inverse
+        self.reparam_offset = reparam_offset
+        self.beta = nn.Parameter(torch.sqrt(torch.ones(channels) + reparam_offset),
+                                 requires_grad=False)
+        # `gamma` [C,C] is never read by the reference's forward (layers.py:13 vs
+        # :19-27); it exists only so that checkpoints load strictly.
+        gamma = torch.sqrt(torch.eye(channels) * gamma_init + reparam_offset)
+        self.gamma = nn.Parameter(gamma, requires_grad=False)
+        self.gamma_conv = _GammaConv(channels, gamma.diag())
+
+    def effective(self):
+        """(beta_eff, gamma_eff) = (beta^2 - off, w^2 - off), layers.py:20-21."""
+        beta = self.beta ** 2 - self.reparam_offset
+        gamma = (self.gamma_conv.weight ** 2 - self.reparam_offset).reshape(-1)
+        return beta.contiguous(), gamma.contiguous()
+
+    @torch.no_grad()
+    def forward(self, x):
+        beta, gamma = self.effective()
+        return ops.gdn_nchw(x, beta, gamma, self.inverse)
+
+
+class _ConvBase(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self._packed = None
+        self._packed_key = None
+
+    def _key(self):
+        w = self.weight
+        return (w._version, w.data_ptr(), str(w.device))
+
+    def packed(self):
+        key = self._key()
+        if self._packed is None or self._packed_key != key:
+            self._packed = self._pack()
+            self._packed_key = key
+        return self._packed
+
+
+class Conv2d(_ConvBase):
+    """nn.Conv2d(in,out,k,stride,padding=(k-1)//2) as built by conv() (layers.py:29-31)."""
+
+    def __init__(self, in_ch, out_ch, k, stride=1):
+        super().__init__()
+        self.in_channels, self.out_channels = in_ch, out_ch
+        self.kernel_size, self.stride = k, stride
+        w = torch.empty(out_ch, in_ch, k, k)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        bound = 1.0 / math.sqrt(in_ch * k * k)
+        self.weight = nn.Parameter(w, requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(out_ch).uniform_(-bound, bound), requires_grad=False)
+
+    def _pack(self):
+        if self.kernel_size == 1:
+            # 1x1 heads run inside dsic_hyper_params: input-major [Cin][Cout]
+            return self.weight.view(self.out_channels, self.in_channels).t().contiguous()
+        return ops.pack_conv_weight(self.weight)
+
+    def run_nhwc(self, x, act=ops.ACT_NONE, gdn=None):
+        beta = gamma = None
+        if gdn is not None:
+            beta, gamma = gdn.effective()
+        return ops.conv2d_nhwc(x, self.packed(), self.bias, self.out_channels, self.kernel_size,
+                               self.stride, act, beta, gamma)
+
+    @torch.no_grad()
+    def forward(self, x):
+        return ops.nhwc_to_nchw(self.run_nhwc(_to_nhwc(x)))
+
+
+def conv(in_ch, out_ch, k, stride=1):
+    """layers.py:29-31."""
+    return Conv2d(in_ch, out_ch, k, stride)
+
+
+class ConvTranspose2d(_ConvBase):
+    """nn.ConvTranspose2d(in,out,5,2,2,output_padding=1) (layers.py:83)."""
+
+    def __init__(self, in_ch, out_ch, kernel_size=5, stride=2, padding=2, output_padding=1):
+        super().__init__()
+        if (kernel_size, stride, padding, output_padding) != (5, 2, 2, 1):
+            raise ValueError("only ConvTranspose2d(k=5, s=2, p=2, output_padding=1) is on the hot path")
+        self.in_channels, self.out_channels = in_ch, out_ch
+        w = torch.empty(in_ch, out_ch, 5, 5)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        bound = 1.0 / math.sqrt(out_ch * 25)
+        self.weight = nn.Parameter(w, requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(out_ch).uniform_(-bound, bound), requires_grad=False)
+
+    @property
+    def to_image(self):
+        return self.out_channels % 8 != 0
+
+    def _pack(self):
+        if self.to_image:
+            return ops.pack_convT_image_weight(self.weight)
+        return ops.pack_convT_weight(self.weight)
+
+    def run_nhwc(self, x, act=ops.ACT_NONE, gdn=None):
+        if self.to_image:   # returns NCHW image
+            return ops.conv_transpose2d_image(x, self.packed(), self.bias, self.out_channels)
+        beta = gamma = None
+        if gdn is not None:
+            beta, gamma = gdn.effective()
+        return ops.conv_transpose2d_nhwc(x, self.packed(), self.bias, self.out_channels, act, beta, gamma)
+
+    @torch.no_grad()
+    def forward(self, x):
+        y = self.run_nhwc(_to_nhwc(x))
+        return y if self.to_image else ops.nhwc_to_nchw(y)
+
+
+def _to_nhwc(x):
+    """NCHW -> NHWC with the channel count padded to a multiple of 8."""
+    if x.dim() != 4:
+        raise ValueError(f"expected [N,C,H,W], got {tuple(x.shape)}")
+    C = x.shape[1]
+    if C <= 8 and C % 8 != 0:
+        return ops.image_to_nhwc8(x)
+    if C % 8 != 0:
+        raise ValueError(f"channel count {C} must be <= 8 or a multiple of 8")
+    return ops.nchw_to_nhwc(x)
+
+
+class _Chain(nn.Sequential):
+    """nn.Sequential whose (conv, GDN|ReLU) pairs run as one fused kernel."""
+
+    def forward_nhwc(self, x, taps=None):
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if isinstance(m, (Conv2d, ConvTranspose2d)):
+                if isinstance(nxt, GDN):
+                    x = m.run_nhwc(x, ops.ACT_IGDN if nxt.inverse else ops.ACT_GDN, nxt)
+                    i += 2
+                elif isinstance(nxt, nn.ReLU):
+                    x = m.run_nhwc(x, ops.ACT_RELU)
+                    i += 2
+                else:
+                    x = m.run_nhwc(x)
+                    i += 1
+            elif isinstance(m, GDN):
+                x = ops.nchw_to_nhwc(m(ops.nhwc_to_nchw(x)))
+                i += 1
+            elif isinstance(m, nn.ReLU):
+                x = torch.relu(x)
+                i += 1
+            else:  # pragma: no cover
+                raise TypeError(f"unsupported module {type(m).__name__}")
+            if taps is not None:
+                taps.append(x)
+        return x
+
+    @torch.no_grad()
+    def forward(self, x):
+        y = self.forward_nhwc(_to_nhwc(x))
+        last = list(self)[-1]
+        if isinstance(last, ConvTranspose2d) and last.to_image:
+            return y
+        return ops.nhwc_to_nchw(y)
+
+
+class AnalysisTransform(nn.Module):
+    """layers.py:46-76: 8 convs (3/1,5/2 alternating) + 7 GDN, /16."""
+
+    def __init__(self, N=128, M=192, in_ch=3):
+        super().__init__()
+        self.g_a = _Chain(
+            conv(in_ch, N, 3, 1), GDN(N),
+            conv(N, N, 5, 2), GDN(N),
+            conv(N, N, 3, 1), GDN(N),
+            conv(N, N, 5, 2), GDN(N),
+            conv(N, N, 3, 1), GDN(N),
+            conv(N, N, 5, 2), GDN(N),
+            conv(N, N, 3, 1), GDN(N),
+            conv(N, M, 5, 2),
+        )
+
+    def forward_nhwc(self, x, taps=None):
+        return self.g_a.forward_nhwc(x, taps)
+
+    def forward(self, x):
+        return self.g_a(x)
+
+
+class SynthesisTransform(nn.Module):
+    """layers.py:78-101: 4 convT + 3 conv + 6 IGDN, x16."""
+
+    def __init__(self, N=128, M=192, out_ch=3):
+        super().__init__()
+        self.g_s = _Chain(
+            ConvTranspose2d(M, N, 5, 2, 2, output_padding=1), GDN(N, inverse=True),
+            conv(N, N, 3, 1), GDN(N, inverse=True),
+            ConvTranspose2d(N, N, 5, 2, 2, output_padding=1), GDN(N, inverse=True),
+            conv(N, N, 3, 1), GDN(N, inverse=True),
+            ConvTranspose2d(N, N, 5, 2, 2, output_padding=1), GDN(N, inverse=True),
+            conv(N, N, 3, 1), GDN(N, inverse=True),
+            ConvTranspose2d(N, out_ch, 5, 2, 2, output_padding=1),
+        )
+
+    def forward_nhwc(self, y_hat, taps=None):
+        """NHWC latents -> NCHW image."""
+        return self.g_s.forward_nhwc(y_hat, taps)
+
+    def forward(self, y_hat):
+        return self.g_s(y_hat)
+
+
+class HyperAnalysis(nn.Module):
+    """layers.py:104-116."""
+
+    def __init__(self, M=192, N=128):
+        super().__init__()
+        self.h_a = _Chain(
+            conv(M, N, 3, 1), nn.ReLU(inplace=True),
+            conv(N, N, 3, 1), nn.ReLU(inplace=True),
+            conv(N, N, 5, 2), nn.ReLU(inplace=True),
+            conv(N, N, 5, 2),
+        )
+
+    def forward_nhwc(self, y, taps=None):
+        return self.h_a.forward_nhwc(y, taps)
+
+    def forward(self, y):
+        return self.h_a(y)
+
+
+class HyperSynthesis(nn.Module):
+    """layers.py:118-152, non-spatial heads (the only branch any reference script uses)."""
+
+    def __init__(self, N=128, M=128, spatial_params=False):
+        super().__init__()
+        if spatial_params:
+            raise NotImplementedError(
+                "spatial_params=True (layers.py:127-129) is outside this round's hot path; "
+                "every reference script runs spatial_params=False (config.py:25)")
+        self.spatial_params = spatial_params
+        self.N, self.M = N, M
+        self.h_s = _Chain(
+            ConvTranspose2d(N, N, 5, 2, 2, output_padding=1), nn.ReLU(inplace=True),
+            ConvTranspose2d(N, N, 5, 2, 2, output_padding=1), nn.ReLU(inplace=True),
+        )
+        self.pool = nn.AdaptiveAvgPool2d(1)
+        self.mlp_sigma = nn.Sequential(Conv2d(N, N, 1), nn.ReLU(), Conv2d(N, M, 1))
+        self.mlp_nu = nn.Sequential(Conv2d(N, N, 1), nn.ReLU(), Conv2d(N, M, 1))
+
+    def params_nhwc(self, z_hat_nhwc, min_nu, max_nu, taps=None):
+        """-> (log_sigma, log_nu, sigma, nu) each [B,M], plus t's spatial size."""
+        t = self.h_s.forward_nhwc(z_hat_nhwc, taps)
+        s0, s2 = self.mlp_sigma[0], self.mlp_sigma[2]
+        n0, n2 = self.mlp_nu[0], self.mlp_nu[2]
+        outs = ops.hyper_params(t, s0.packed(), s0.bias, s2.packed(), s2.bias, n0.packed(), n0.bias,
+                                n2.packed(), n2.bias, self.M, min_nu, max_nu)
+        return outs, (t.shape[1], t.shape[2])
+
+    @torch.no_grad()
+    def forward(self, z):
+        # clamp bounds are irrelevant for the log outputs returned here
+        (log_sigma, log_nu, _, _), (Ht, Wt) = self.params_nhwc(_to_nhwc(z), 0.0, float("inf"))
+        B = z.shape[0]
+        return (log_sigma.view(B, self.M, 1, 1).expand(-1, -1, Ht, Wt),
+                log_nu.view(B, self.M, 1, 1).expand(-1, -1, Ht, Wt))

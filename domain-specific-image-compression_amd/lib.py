@@ -33,6 +33,13 @@ SIGNATURES = {
     "dsic_conv_transpose2d_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int,
                                            c_int, c_int, _P]),
     "dsic_conv_transpose2d_image": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "dsic_hyper_params": (c_int, [_P] * 13 + [c_int, c_int, c_int, c_int, ctypes.c_float,
+                                     ctypes.c_float, _P]),
+    "dsic_rate": (c_int, [_P] * 13 + [c_int, c_int, c_int, c_int, c_int, _P]),
+    "dsic_student_t_bits": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P]),
+    "dsic_gaussian_bits": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+    "dsic_round": (c_int, [_P, _P, c_int64, _P]),
+    "dsic_gdn_nchw": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
 }
 
 _lib = None

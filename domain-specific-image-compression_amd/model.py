@@ -1,0 +1,110 @@
+"""Mirror of code/modelv2/model.py: CompressionModel and rate_distortion_loss.
+
+forward() keeps activations NHWC on the device from the first conv to the last
+and launches only HIP kernels of libdsic_hip.so; the returned dict has the
+reference's nine keys with the reference's NCHW shapes (model.py:65-72).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .distributions import FactorizedGaussian, StudentT
+from .layers import AnalysisTransform, HyperAnalysis, HyperSynthesis, SynthesisTransform, _to_nhwc
+
+
+class ForwardOutput(dict):
+    """The reference's output dict plus device-side per-image sums.
+
+    `sums` is [B,2] float64 = (sum nll_y, sum nll_z) per image, so evaluators can
+    form bpp without re-reducing nll tensors on the host (modelseval.py:90-94).
+    """
+    sums = None
+    layer_taps = None
+
+
+class CompressionModel(nn.Module):
+    def __init__(self, N=128, M=192, spatial_params=False, min_nu=1.1, max_nu=100.0, in_ch=3):
+        super().__init__()
+        self.g_a = AnalysisTransform(N, M, in_ch=in_ch)
+        self.g_s = SynthesisTransform(N, M, out_ch=in_ch)
+        self.h_a = HyperAnalysis(M, N)
+        self.h_s = HyperSynthesis(N, M, spatial_params=spatial_params)
+        self.studentT = StudentT()
+        self.z_prior = FactorizedGaussian(N)
+        self.min_nu = min_nu
+        self.max_nu = max_nu
+        self.spatial_params = spatial_params
+        self.N, self.M = N, M
+
+    @staticmethod
+    def quantize(x, mode):
+        """model.py:27-35."""
+        if mode == "noise":
+            return x + torch.empty_like(x).uniform_(-0.5, 0.5)
+        elif mode == "round":
+            return ops.round_half_even(x)
+        else:
+            raise ValueError(f"Unknown quant mode: {mode}")
+
+    @torch.no_grad()
+    def forward(self, x, quant_mode="noise", collect_taps=False):
+        """model.py:37-72.  x: [B,C,H,W] float32 on the GPU, H and W multiples of 16."""
+        if quant_mode not in ("noise", "round"):
+            raise ValueError(f"Unknown quant mode: {quant_mode}")
+        if x.dim() != 4:
+            raise ValueError(f"expected [N,C,H,W], got {tuple(x.shape)}")
+        B, _, H, W = x.shape
+        taps = [] if collect_taps else None
+        x_nhwc = _to_nhwc(x)
+        y = self.g_a.forward_nhwc(x_nhwc, taps)            # [B,H/16,W/16,M]
+        z = self.h_a.forward_nhwc(y, taps)                 # [B,.,.,N]
+        y_noisy = z_noisy = None
+        if quant_mode == "noise":
+            y_noisy = self.quantize(y, "noise")
+            z_noisy = self.quantize(z, "noise")
+            z_in = z_noisy
+        else:
+            z_in = ops.round_half_even(z)
+        (log_sigma, log_nu, sigma, nu), _ = self.h_s.params_nhwc(z_in, self.min_nu, self.max_nu, taps)
+        r = ops.rate(y, z, sigma, nu, self.z_prior.log_sigma, y_noisy, z_noisy)
+        # model.py:62: eval mode synthesises from round(y), training from y_tilde
+        y_hat = r["y_hat_nhwc"] if not self.training else (y_noisy if y_noisy is not None else r["y_hat_nhwc"])
+        x_hat = self.g_s.forward_nhwc(y_hat, taps)
+        Hy, Wy = y.shape[1], y.shape[2]
+        out = ForwardOutput({
+            "x_hat": x_hat,
+            "nll_y": r["nll_y"],
+            "nll_z": r["nll_z"],
+            "y": ops.nhwc_to_nchw(y), "y_tilde": r["y_tilde"],
+            "z": ops.nhwc_to_nchw(z), "z_tilde": r["z_tilde"],
+            "sigma": sigma.view(B, self.M, 1, 1).expand(-1, -1, Hy, Wy),
+            "nu": nu.view(B, self.M, 1, 1).expand(-1, -1, Hy, Wy),
+        })
+        out.sums = r["sums"]
+        out.layer_taps = taps
+        return out
+
+
+def rate_distortion_loss(out, x, lambda_rd=10000.0, dist="mssim"):
+    """model.py:75-107: returns (loss, R, D) with R = clamp(sum nll / (N*H*W), 0)."""
+    from . import metrics
+    N, C, H, W = x.shape
+    if dist not in ("mse", "msssim"):
+        raise ValueError("dist must be 'mse' or 'msssim'")
+    sums = getattr(out, "sums", None)
+    if sums is not None:
+        total = sums.sum()
+    else:
+        total = out["nll_y"].double().sum() + out["nll_z"].double().sum()
+    R = torch.clamp(total / (N * H * W), min=0.0).float()
+    x_hat = out["x_hat"]
+    if dist == "mse":
+        D = metrics.mse(x_hat, x)
+    else:
+        if x_hat.shape[2:] != x.shape[2:]:
+            raise ValueError("msssim: x_hat and x must have the same size (crop or pad first)")
+        D = 1.0 - metrics.ms_ssim(x_hat.clamp(0, 1), x, data_range=1.0, weights=(0.3, 0.5, 0.2))
+    loss = lambda_rd * D + R
+    return loss, R, D

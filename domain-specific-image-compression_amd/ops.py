@@ -126,3 +126,86 @@ def conv_transpose2d_image(x, w_packed, bias, Cimg, out=None):
     _lib.check(_lib.load().dsic_conv_transpose2d_image(_p(x), _p(w_packed), _p(bias), _p(out), B, H, W,
                                                        Cin, Cimg, _stream()), "conv_transpose2d_image")
     return out
+
+
+def round_half_even(x: torch.Tensor) -> torch.Tensor:
+    """quantize(x, "round") (model.py:32-33)."""
+    x = _f32c(x, "round")
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().dsic_round(_p(x), _p(out), x.numel(), _stream()), "round")
+    return out
+
+
+def gdn_nchw(x, beta_eff, gamma_eff, inverse: bool):
+    """Stand-alone GDN / IGDN on NCHW (layers.py:19-27)."""
+    x = _f32c(x, "gdn")
+    B, C, H, W = x.shape
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().dsic_gdn_nchw(_p(x), _p(beta_eff), _p(gamma_eff), _p(out), B, C, H * W,
+                                         int(bool(inverse)), _stream()), "gdn")
+    return out
+
+
+def hyper_params(t_nhwc, w1s, b1s, w2s, b2s, w1n, b1n, w2n, b2n, M, min_nu, max_nu):
+    """pool + MLP heads + exp/clamp -> (log_sigma, log_nu, sigma, nu), each [B,M]."""
+    t = _f32c(t_nhwc, "hyper_params")
+    B, H, W, N = t.shape
+    outs = [torch.empty((B, M), dtype=torch.float32, device=t.device) for _ in range(4)]
+    _lib.check(_lib.load().dsic_hyper_params(_p(t), _p(w1s), _p(b1s), _p(w2s), _p(b2s), _p(w1n), _p(b1n),
+                                             _p(w2n), _p(b2n), _p(outs[0]), _p(outs[1]), _p(outs[2]),
+                                             _p(outs[3]), B, H * W, N, M, float(min_nu), float(max_nu),
+                                             _stream()), "hyper_params")
+    return outs
+
+
+def rate(y_nhwc, z_nhwc, sigma, nu, z_log_sigma, y_noisy=None, z_noisy=None):
+    """round + Student-t/Gaussian bits + per-image sums.
+
+    Returns dict(y_hat_nhwc, y_tilde, z_tilde, nll_y, nll_z (NCHW), sums [B,2] fp64).
+    """
+    y = _f32c(y_nhwc, "rate")
+    z = _f32c(z_nhwc, "rate")
+    B, Hy, Wy, M = y.shape
+    _, Hz, Wz, N = z.shape
+    dev = y.device
+    y_hat = torch.empty_like(y)
+    y_t = torch.empty((B, M, Hy, Wy), dtype=torch.float32, device=dev)
+    nll_y = torch.empty_like(y_t)
+    z_t = torch.empty((B, N, Hz, Wz), dtype=torch.float32, device=dev)
+    nll_z = torch.empty_like(z_t)
+    sums = torch.empty((B, 2), dtype=torch.float64, device=dev)
+    _lib.check(_lib.load().dsic_rate(_p(y), _p(z), _p(y_noisy), _p(z_noisy), _p(sigma), _p(nu),
+                                     _p(z_log_sigma), _p(y_hat), _p(y_t), _p(z_t), _p(nll_y), _p(nll_z),
+                                     _p(sums), B, Hy * Wy, M, Hz * Wz, N, _stream()), "rate")
+    return {"y_hat_nhwc": y_hat, "y_tilde": y_t, "z_tilde": z_t, "nll_y": nll_y, "nll_z": nll_z,
+            "sums": sums}
+
+
+def student_t_bits(x, sigma, nu):
+    """StudentT.neg_log2_prob on NCHW x; sigma/nu full-shape or spatially constant."""
+    x = _f32c(x, "student_t_bits")
+    B, C, H, W = x.shape
+    per_channel = 0
+    if sigma.dim() == 4 and sigma.stride(2) == 0 and sigma.stride(3) == 0 \
+            and nu.dim() == 4 and nu.stride(2) == 0 and nu.stride(3) == 0:
+        sigma = sigma[:, :, 0, 0].expand(B, C)
+        nu = nu[:, :, 0, 0].expand(B, C)
+        per_channel = 1
+    else:
+        sigma = sigma.expand_as(x)
+        nu = nu.expand_as(x)
+    sigma = _f32c(sigma, "student_t_bits")
+    nu = _f32c(nu, "student_t_bits")
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().dsic_student_t_bits(_p(x), _p(sigma), _p(nu), _p(out), x.numel(), H * W,
+                                               per_channel, _stream()), "student_t_bits")
+    return out
+
+
+def gaussian_bits(x, log_sigma):
+    x = _f32c(x, "gaussian_bits")
+    B, C, H, W = x.shape
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().dsic_gaussian_bits(_p(x), _p(_f32c(log_sigma, "gaussian_bits")), _p(out), B, C,
+                                              H * W, _stream()), "gaussian_bits")
+    return out

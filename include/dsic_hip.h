@@ -97,6 +97,55 @@ int dsic_conv_transpose2d_image(const float* in, const float* w_packed,
                                 const float* bias, float* out_nchw, int B,
                                 int H, int W, int Cin, int Cimg, void* stream);
 
+/* ---- hyper-synthesis heads, quantisation, rate --------------------------- */
+
+/* AdaptiveAvgPool2d(1) -> mlp_sigma / mlp_nu (1x1 conv, ReLU, 1x1 conv)
+ * (layers.py:131-139,147-151), then sigma = exp(log_sigma),
+ * nu = clamp(exp(log_nu), min_nu, max_nu) (model.py:54-55; the spatial mean
+ * of a spatially constant tensor is the tensor).  t: NHWC [B,HW,N] = ReLU
+ * output of h_s.  1x1 weights are passed INPUT-major: w1 [N][N], w2 [N][M]
+ * (= reference weight[o,i,0,0] transposed).  Outputs [B,M]. */
+int dsic_hyper_params(const float* t_nhwc, const float* w1_sigma,
+                      const float* b1_sigma, const float* w2_sigma,
+                      const float* b2_sigma, const float* w1_nu,
+                      const float* b1_nu, const float* w2_nu,
+                      const float* b2_nu, float* log_sigma, float* log_nu,
+                      float* sigma, float* nu, int B, int HW, int N, int M,
+                      float min_nu, float max_nu, void* stream);
+
+/* quantize("round") (model.py:27-35, 44-45, 62), StudentT.neg_log2_prob
+ * (distributions.py:20-31), FactorizedGaussian.neg_log2_prob
+ * (distributions.py:39-46) and the per-image sums behind model.py:76.
+ * y NHWC [B,HWy,M], z NHWC [B,HWz,N]; sigma, nu [B,M]; z_log_sigma [N].
+ * y_noisy/z_noisy (NHWC, may be NULL): when given they ARE y_tilde/z_tilde
+ * (quant_mode="noise"), otherwise y_tilde = round(y).  Outputs: y_hat NHWC
+ * (= round(y), the synthesis input), y_tilde/z_tilde/nll_y/nll_z in the
+ * reference's NCHW, sums[B][2] = {sum nll_y, sum nll_z} as fp64. */
+int dsic_rate(const float* y_nhwc, const float* z_nhwc,
+              const float* y_noisy_nhwc, const float* z_noisy_nhwc,
+              const float* sigma, const float* nu, const float* z_log_sigma,
+              float* y_hat_nhwc, float* y_tilde_nchw, float* z_tilde_nchw,
+              float* nll_y_nchw, float* nll_z_nchw, double* sums, int B,
+              int HWy, int M, int HWz, int N, void* stream);
+
+/* StudentT.neg_log2_prob (distributions.py:20-31) elementwise on NCHW x[n].
+ * per_channel=1: sigma/nu are [B*C] (spatially constant, HW elements each);
+ * per_channel=0: sigma/nu are full tensors of n elements. */
+int dsic_student_t_bits(const float* x, const float* sigma, const float* nu,
+                        float* out, int64_t n, int HW, int per_channel,
+                        void* stream);
+/* FactorizedGaussian.neg_log2_prob (distributions.py:39-46), x NCHW. */
+int dsic_gaussian_bits(const float* x, const float* log_sigma, float* out,
+                       int B, int C, int HW, void* stream);
+
+/* torch.round (half to even) elementwise: quantize(x,"round"), model.py:32-33 */
+int dsic_round(const float* x, float* out, int64_t n, void* stream);
+
+/* Stand-alone GDN (inverse=0) / IGDN (inverse=1) on NCHW (layers.py:19-27);
+ * beta/gamma are the effective per-channel values. */
+int dsic_gdn_nchw(const float* x, const float* beta, const float* gamma,
+                  float* out, int B, int C, int HW, int inverse, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
