@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 256x256x3 satellite patches through the modelv2 hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+
+One "step" = one pass of the hot path over one batch of B synthetic patches per
+GPU (inputs resident in HBM before the timed region): analysis -> hyper-analysis
+-> round -> hyper-synthesis -> Student-t/Gaussian rate -> synthesis, per-image
+bpp (+ MS-SSIM when metrics are built), then the cross-GPU all-reduce of the
+metric sums.  Prints ONE JSON line on rank 0 (contract in the task statement).
+
+For N > 1 the driver launches this file with torch.distributed.run, one rank
+per GPU; images are sharded by global index, there is no data-path collective.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FLOP_PER_IMAGE_256 = 36.211e9        # 18.105 GMAC, conv/convT MACs x 2
+PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: fp32-input MFMA peak
+PEAK_HBM_GBS = 8000.0
+
+
+class KernelTimer:
+    """HIP-event pairs around chosen launches on the launching stream."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []
+
+    def record(self, name, flops, launch):
+        if not self.enabled:
+            return launch()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = launch()
+        e1.record()
+        self.records.append((name, flops, e0, e1))
+        return r
+
+    def summary(self):
+        agg = {}
+        for name, flops, e0, e1 in self.records:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += flops
+        return agg
+
+
+def cpu_baseline(sd, patches, H, W, threads):
+    """Oracle (eager fp32 restatement of the reference forward) on the host cores:
+    one image per call like modelseval.py:158-173."""
+    from oracle import ref_model as O
+    torch.set_num_threads(threads)
+    imgs = [torch.from_numpy(patches[i:i + 1]) for i in range(min(4, len(patches)))]
+    for i in range(2):
+        O.forward(sd, imgs[i % len(imgs)], "round")
+    times = []
+    n = 0
+    t_start = time.perf_counter()
+    while n < 12 and time.perf_counter() - t_start < 25.0:
+        t0 = time.perf_counter()
+        out = O.forward(sd, imgs[n % len(imgs)], "round")
+        float((out["nll_y"].sum() + out["nll_z"].sum()) / (H * W))
+        times.append(time.perf_counter() - t0)
+        n += 1
+    return 1.0 / float(np.median(times)), n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="patches per GPU per step")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--channels", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+
+    from dsic_amd import metrics, ops, synthetic as S
+    from dsic_amd.model import CompressionModel
+
+    B, H, W, C = args.batch, args.size, args.size, args.channels
+    sd = S.make_state_dict(seed=S.WEIGHT_SEED, in_ch=C)
+    model = CompressionModel(N=128, M=192, spatial_params=False, min_nu=2, max_nu=100.0, in_ch=C)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model = model.to(dev).eval()
+    # this rank's slice of the global batch, resident in HBM before timing
+    patches = S.make_patches(rank * B, B, H, W, C)
+    x = torch.from_numpy(patches).to(dev)
+
+    timer = KernelTimer()
+    ops.set_kernel_timer(timer)
+    totals = torch.zeros(3, dtype=torch.float64, device=dev)
+
+    def step():
+        out = model(x, quant_mode="round")
+        bpp = out.sums.sum(dim=1) / float(H * W)                 # per image (modelseval.py:90-94)
+        msssim = metrics.ms_ssim_per_image(out["x_hat"], x, clamp_x=True)
+        t = torch.stack([bpp.sum(), msssim.double().sum(),
+                         torch.tensor(float(B), dtype=torch.float64, device=dev)])
+        if world > 1:
+            dist.all_reduce(t)                                   # the one collective: 3 x fp64
+        totals.copy_(t)
+        return out
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    tot = totals.cpu().numpy()
+    n_img = tot[2]
+    value = args.steps * B * world / elapsed
+
+    if rank == 0:
+        agg = timer.summary()
+        name, (cnt, secs, flops) = max(agg.items(), key=lambda kv: kv[1][1])
+        achieved = flops / secs / 1e12
+        conv_secs = sum(v[1] for v in agg.values())
+        pmc = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                pmc = json.load(f).get(name)
+        res = {
+            "metric": "256x256 satellite patches encoded/s per GPU; bpp + MS-SSIM vs reference",
+            "value": value,
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"batch={B}/GPU {H}x{W}x{C} synthetic patches, modelv2 encode->decode "
+                            "(g_a,h_a,round,h_s,Student-t/Gaussian rate,g_s) + bpp + MS-SSIM[.3,.5,.2] on GPU",
+                "global_batch": B * world,
+                "parallelism": f"per-image sharding x{world}, one all-reduce of 3 fp64",
+                "weights": "synthetic seed 1 (checkpoints absent from the reference)",
+            },
+            "mean_bpp": float(tot[0] / n_img),
+            "mean_ms_ssim": float(tot[1] / n_img),
+            "images_per_s_per_gpu": value / world,
+            "roofline": {
+                "bound": "mfma",
+                "kernel": name,
+                "launches": cnt,
+                "avg_launch_ms": secs / cnt * 1e3,
+                "achieved": achieved,
+                "peak": PEAK_FP32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                "traffic": pmc,
+                "all_conv_tflops": sum(v[2] for v in agg.values()) / conv_secs / 1e12,
+                "conv_share_of_step": conv_secs / elapsed,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline and (H, W) == (256, 256):
+            # the GPU box gives one job a 16-CPU share of a larger host
+            cores = min(len(os.sched_getaffinity(0)), 16)
+            v_all, n_all = cpu_baseline(sd, patches, H, W, cores)
+            v_one, n_one = cpu_baseline(sd, patches, H, W, 1)
+            res["cpu_baseline"] = {
+                "value": v_all, "unit": "images/s", "cores": cores, "kind": "port",
+                "sample": f"{n_all} single-image eager-fp32 forwards (oracle/ref_model.py, verified against the "
+                          f"reference in the build container) + bpp, median; 1 thread: {v_one:.3f} images/s "
+                          f"over {n_one} images (cpu.sbatch:5 requests 1 CPU)",
+                "value_1thread": v_one,
+            }
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -27,6 +27,8 @@
 // Transposed 5x5/s2 convolutions run as their four sub-pixel phases
 // (blockIdx.y): phase (py,px) is a stride-1 conv over the input grid with
 // (3-py)x(3-px) taps whose outputs land on (2*oy+py, 2*ox+px): no zero MACs.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dsic {
@@ -53,6 +55,7 @@ struct ConvArgs {
   int out_mode;
   int Cimg;           // OUT_IMAGE_NCHW: image channels (columns = 4*Cimg)
   int tiles_x, tiles_y;
+  int dbg;            // diagnostic ablation bits (0 in production)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float beta, float gamma) {
@@ -85,7 +88,10 @@ __global__ __launch_bounds__(256, NTW == 2 ? 1 : 2) void conv_igemm_kernel(const
   constexpr int MTW = NARROW ? 1 : 4;  // M tiles per wave
   constexpr int PAD = (WIN - 1) / 2;
 
-  __shared__ __attribute__((aligned(16))) float lds[NPIX * P];
+  constexpr int EPI_STRIDE = 36;                    // floats per row of the epilogue transpose tile
+  constexpr int EPI_FLOATS = 4 * 32 * EPI_STRIDE;   // one 32x32 tile per wave
+  constexpr int LDS_FLOATS = NPIX * P > EPI_FLOATS ? NPIX * P : EPI_FLOATS;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -150,6 +156,8 @@ __global__ __launch_bounds__(256, NTW == 2 ? 1 : 2) void conv_igemm_kernel(const
   }
 
   // ---- B fragment lane offsets ---------------------------------------------
+  // A wave whose column tile lies beyond CoutP recomputes tile 0 (in-bounds
+  // weights) and drops the result in the epilogue: keeps the MFMA loop branch-free.
   int ntile[NTW];
   bool nvalid[NTW];
   int boff[NTW];
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(256, NTW == 2 ? 1 : 2) void conv_igemm_kernel(const
   for (int j = 0; j < NTW; ++j) {
     ntile[j] = NARROW ? 0 : wave + 4 * j;
     nvalid[j] = ntile[j] * 32 < a.CoutP;
-    boff[j] = (ntile[j] * 32 + l31) * 8 + 4 * h;
+    boff[j] = ((nvalid[j] ? ntile[j] : 0) * 32 + l31) * 8 + 4 * h;
   }
   const int wstep = a.CoutP * 8;  // floats per (tap, 8-channel) slab
 
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(256, NTW == 2 ? 1 : 2) void conv_igemm_kernel(const
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) {
       floatx4 v = {0.f, 0.f, 0.f, 0.f};
-      if (goff[i] >= 0) v = *(const floatx4*)(in_tile + goff[i] + chunk * CK);
+      if (goff[i] >= 0 && !(a.dbg & 1)) v = *(const floatx4*)(in_tile + goff[i] + chunk * CK);
       stage[i] = v;
     }
   };
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(256, NTW == 2 ? 1 : 2) void conv_igemm_kernel(const
   for (int chunk = 0; chunk < nchunks; ++chunk) {
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i)
-      if (loff[i] >= 0) *(floatx4*)(lds + loff[i]) = stage[i];
+      if (loff[i] >= 0 && !(a.dbg & 2)) *(floatx4*)(lds + loff[i]) = stage[i];
     __syncthreads();
     if (chunk + 1 < nchunks) issue_chunk(chunk + 1);
 
@@ -192,81 +200,122 @@ __global__ __launch_bounds__(256, NTW == 2 ? 1 : 2) void conv_igemm_kernel(const
     const float* wchunk = a.w + (size_t)(tapbase * Cin8 + chunk * NSUB) * wstep;
     const int nsteps = nty * ntx * NSUB;
 
-    floatx4 bcur[NTW], bnxt[NTW];
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-      bcur[j] = floatx4{0.f, 0.f, 0.f, 0.f};
-      if (nvalid[j]) bcur[j] = *(const floatx4*)(wchunk + boff[j]);
-      bnxt[j] = bcur[j];
-    }
-    int ty = 0, tx = 0, sub = 0;       // current step
-    int nty_ = 0, ntx_ = 0, nsub_ = 0;  // next step (for the B prefetch)
-    for (int step = 0; step < nsteps; ++step) {
-      // advance the "next" cursor and prefetch its B fragments
-      nsub_++;
-      if (nsub_ == NSUB) {
-        nsub_ = 0;
-        ntx_++;
-        if (ntx_ == ntx) {
-          ntx_ = 0;
-          nty_++;
+    // Two operand sets in ping-pong: the set of step k+1 is loaded (LDS for A,
+    // L2 for B) before the 16 MFMAs of step k issue, so no load latency sits
+    // between MFMA clusters and no register copies are needed.
+    floatx4 a0[MTW], a1[MTW], b0[NTW], b1[NTW];
+    int ty = 0, tx = 0, sub = 0;  // cursor of the step whose operands are loaded next
+    auto advance = [&]() {
+      sub++;
+      if (sub == NSUB) {
+        sub = 0;
+        tx++;
+        if (tx == ntx) {
+          tx = 0;
+          ty++;
         }
       }
-      if (step + 1 < nsteps) {
-        const float* wn = wchunk + (size_t)((nty_ * ntx + ntx_) * Cin8 + nsub_) * wstep;
+    };
+    auto load_ops = [&](floatx4(&A)[MTW], floatx4(&Bf)[NTW]) {
+      const float* wn = wchunk + (size_t)((ty * ntx + tx) * Cin8 + sub) * wstep;
 #pragma unroll
-        for (int j = 0; j < NTW; ++j)
-          if (nvalid[j]) bnxt[j] = *(const floatx4*)(wn + boff[j]);
-      }
-      // A fragments of the current step
+      for (int j = 0; j < NTW; ++j)
+        if (!(a.dbg & 4)) Bf[j] = *(const floatx4*)(wn + boff[j]);
       const int aoff = ((ty + wy0) * TWIN + (tx + wx0)) * P + sub * 8;
-      floatx4 af[MTW];
 #pragma unroll
-      for (int m = 0; m < MTW; ++m) af[m] = *(const floatx4*)(lds + abase[m] + aoff);
+      for (int m = 0; m < MTW; ++m) A[m] = *(const floatx4*)(lds + abase[m] + aoff);
+    };
+    auto mfma16 = [&](const floatx4(&A)[MTW], const floatx4(&Bf)[NTW]) {
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
         for (int j = 0; j < NTW; ++j)
 #pragma unroll
           for (int m = 0; m < MTW; ++m)
-            if (nvalid[j])
-              acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][s], bcur[j][s], acc[m][j], 0, 0, 0);
+            acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[m][s4], Bf[j][s4], acc[m][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) bcur[j] = bnxt[j];
-      ty = nty_;
-      tx = ntx_;
-      sub = nsub_;
+    for (int j = 0; j < NTW; ++j) b0[j] = b1[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    load_ops(a0, b0);
+    int step = 0;
+    for (; step + 2 <= nsteps; step += 2) {
+      advance();
+      load_ops(a1, b1);
+      mfma16(a0, b0);
+      advance();
+      if (step + 2 < nsteps) load_ops(a0, b0);
+      mfma16(a1, b1);
     }
+    if (step < nsteps) mfma16(a0, b0);
     __syncthreads();
   }
 
+  if (a.dbg & 8) {
+    if (acc[0][0][0] == 123.456f) a.out[0] = 1.f;
+    return;
+  }
   // ---- epilogue: bias + activation, store --------------------------------
-  // C/D map of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+  // C/D map of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5):
+  // a lane owns ONE channel of 16 pixels.  NHWC wants the opposite (one pixel,
+  // consecutive channels per lane), so each wave transposes its 32x32 tile
+  // through a private LDS patch and stores 16 bytes per lane: 4 store
+  // instructions per tile instead of 16.
+  float* epi = lds + wave * (32 * EPI_STRIDE);
 #pragma unroll
   for (int j = 0; j < NTW; ++j) {
     if (!nvalid[j]) continue;
     const int n = ntile[j] * 32 + l31;
     if (a.out_mode == OUT_NHWC) {
-      if (n >= a.Cout) continue;
-      const float bias = a.bias[n];
-      float beta = 0.f, gamma = 0.f;
-      if (a.act == DSIC_ACT_GDN || a.act == DSIC_ACT_IGDN) {
+      const bool nok = n < a.Cout;
+      const float bias = nok ? a.bias[n] : 0.f;
+      float beta = 1.f, gamma = 0.f;
+      if (nok && (a.act == DSIC_ACT_GDN || a.act == DSIC_ACT_IGDN)) {
         beta = a.beta[n];
         gamma = a.gamma[n];
       }
+      const bool wide = (a.Cout & 3) == 0;
 #pragma unroll
       for (int m = 0; m < MTW; ++m) {
         const int mt = NARROW ? wave : m;
+        if (wide) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int r = mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          const int ox = ox0 + r % TOW;
-          const int oy = oy0 + (r / TOW) % TOH;
-          const int ni = n0 + r / (TOW * TOH);
-          if (ni < a.B && oy < a.Ho && ox < a.Wo) {
-            const float v = apply_act(__fadd_rn(acc[m][j][e], bias), a.act, beta, gamma);
-            const size_t o = (((size_t)ni * a.oH + (oy * a.os + py)) * a.oW + (ox * a.os + px)) * a.Cout + n;
-            a.out[o] = v;
+          for (int e = 0; e < 16; ++e) {
+            const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
+            epi[rr * EPI_STRIDE + l31] = apply_act(__fadd_rn(acc[m][j][e], bias), a.act, beta, gamma);
+          }
+          // same-wave LDS round trip: program order + lgkmcnt wait suffice
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          __builtin_amdgcn_wave_barrier();
+          const int c4 = (lane & 7) * 4;
+          const int nn = ntile[j] * 32 + c4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int rr = (lane >> 3) + 8 * i;
+            const floatx4 v = *(const floatx4*)(epi + rr * EPI_STRIDE + c4);
+            const int r = mt * 32 + rr;
+            const int ox = ox0 + r % TOW;
+            const int oy = oy0 + (r / TOW) % TOH;
+            const int ni = n0 + r / (TOW * TOH);
+            if (ni < a.B && oy < a.Ho && ox < a.Wo && nn < a.Cout) {
+              const size_t o = (((size_t)ni * a.oH + (oy * a.os + py)) * a.oW + (ox * a.os + px)) * a.Cout + nn;
+              *(floatx4*)(a.out + o) = v;
+            }
+          }
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          __builtin_amdgcn_wave_barrier();
+        } else if (nok) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int r = mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const int ox = ox0 + r % TOW;
+            const int oy = oy0 + (r / TOW) % TOH;
+            const int ni = n0 + r / (TOW * TOH);
+            if (ni < a.B && oy < a.Ho && ox < a.Wo) {
+              const size_t o = (((size_t)ni * a.oH + (oy * a.os + py)) * a.oW + (ox * a.os + px)) * a.Cout + n;
+              a.out[o] = apply_act(__fadd_rn(acc[m][j][e], bias), a.act, beta, gamma);
+            }
           }
         }
       }
@@ -330,6 +379,10 @@ static int run_conv_ck(ConvArgs& a, int nphase, hipStream_t st) {
 }
 
 static int run_conv(ConvArgs& a, int win, int stride, int nphase, hipStream_t st) {
+  {
+    const char* d = getenv("DSIC_DBG");
+    a.dbg = d ? atoi(d) : 0;
+  }
   if (win == 3 && stride == 1)
     return a.Cin % 32 == 0 ? run_conv_ck<3, 1, 32>(a, nphase, st) : run_conv_ck<3, 1, 8>(a, nphase, st);
   if (win == 5 && stride == 2)

@@ -95,7 +95,7 @@ class Conv2d(_ConvBase):
         if gdn is not None:
             beta, gamma = gdn.effective()
         return ops.conv2d_nhwc(x, self.packed(), self.bias, self.out_channels, self.kernel_size,
-                               self.stride, act, beta, gamma)
+                               self.stride, act, beta, gamma, cin_real=self.in_channels)
 
     @torch.no_grad()
     def forward(self, x):

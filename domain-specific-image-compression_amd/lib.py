@@ -40,6 +40,12 @@ SIGNATURES = {
     "dsic_gaussian_bits": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "dsic_round": (c_int, [_P, _P, c_int64, _P]),
     "dsic_gdn_nchw": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "dsic_ssim_partial_doubles": (c_int64, [c_int, c_int, c_int]),
+    "dsic_ssim_level": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, ctypes.c_float, ctypes.c_float,
+                                c_int, _P]),
+    "dsic_avgpool2": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "dsic_msssim_finalize": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "dsic_sqerr_per_image": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P]),
 }
 
 _lib = None
@@ -54,6 +60,11 @@ def load() -> ctypes.CDLL:
                 f"{LIB_PATH} is missing: build it with "
                 "`python domain-specific-image-compression_amd/build.py` "
                 "(or __graft_entry__.build()); there is no CPU fallback")
+        # torch bundles its own HIP runtime (torch/lib/libamdhip64.so); import it
+        # first so this library binds to the SAME runtime instance that owns the
+        # streams and allocations (loading /opt/rocm's copy beside it gives
+        # "no ROCm-capable device").
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

@@ -29,6 +29,38 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
+# Optional per-launch timer (bench.py): object with .record(tag, flops, launch)
+# where launch() enqueues the kernel on the current stream.
+_kernel_timer = None
+
+
+def set_kernel_timer(timer):
+    global _kernel_timer
+    _kernel_timer = timer
+
+
+def _conv_kernel_name(win, stride, Wo, Cin, CoutP):
+    """Template instantiation conv_igemm.hip dispatches to (for profile matching)."""
+    ck = (32 if Cin % 32 == 0 else 8) if win == 3 else (16 if Cin % 16 == 0 else 8)
+    if Wo > 8:
+        tile = (16, 8, 1)
+    elif Wo > 4:
+        tile = (8, 8, 2)
+    else:
+        tile = (4, 4, 8)
+        if win == 5:
+            ck = 8
+    nt = CoutP // 32
+    ntw, narrow = (1, 1) if nt == 1 else ((1, 0) if nt <= 4 else (2, 0))
+    return f"conv_igemm_kernel<{win},{stride},{tile[0]},{tile[1]},{tile[2]},{ck},{ntw},{narrow}>"
+
+
+def _timed(name, flops, launch):
+    if _kernel_timer is None:
+        return launch()
+    return _kernel_timer.record(name, flops, launch)
+
+
 def round_up(a: int, b: int) -> int:
     return (a + b - 1) // b * b
 
@@ -92,16 +124,20 @@ def nchw_to_nhwc(x: torch.Tensor) -> torch.Tensor:
     return dst
 
 
-def conv2d_nhwc(x, w_packed, bias, Cout, k, stride, act=ACT_NONE, beta=None, gamma=None, out=None):
+def conv2d_nhwc(x, w_packed, bias, Cout, k, stride, act=ACT_NONE, beta=None, gamma=None, out=None,
+                cin_real=None):
     """conv() + fused activation on NHWC activations (layers.py:29-31)."""
     x = _f32c(x, "conv2d_nhwc")
     B, H, W, CinP = x.shape
     Ho, Wo = -(-H // stride), -(-W // stride)
     if out is None:
         out = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().dsic_conv2d_nhwc(_p(x), _p(w_packed), _p(bias), _p(beta), _p(gamma), _p(out),
-                                            B, H, W, CinP, Cout, k, stride, act, _stream()),
-               "conv2d_nhwc")
+    L = _lib.load()
+    _timed(_conv_kernel_name(k, stride, Wo, CinP, round_up(Cout, 32)),
+           2.0 * B * Ho * Wo * Cout * (cin_real or CinP) * k * k,
+           lambda: _lib.check(L.dsic_conv2d_nhwc(_p(x), _p(w_packed), _p(bias), _p(beta), _p(gamma),
+                                                 _p(out), B, H, W, CinP, Cout, k, stride, act, _stream()),
+                              "conv2d_nhwc"))
     return out
 
 
@@ -111,9 +147,12 @@ def conv_transpose2d_nhwc(x, w_packed, bias, Cout, act=ACT_NONE, beta=None, gamm
     B, H, W, Cin = x.shape
     if out is None:
         out = torch.empty((B, 2 * H, 2 * W, Cout), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().dsic_conv_transpose2d_nhwc(_p(x), _p(w_packed), _p(bias), _p(beta), _p(gamma),
-                                                      _p(out), B, H, W, Cin, Cout, act, _stream()),
-               "conv_transpose2d_nhwc")
+    L = _lib.load()
+    _timed(_conv_kernel_name(3, 1, W, Cin, round_up(Cout, 32)),
+           2.0 * B * H * W * Cout * Cin * 25,
+           lambda: _lib.check(L.dsic_conv_transpose2d_nhwc(_p(x), _p(w_packed), _p(bias), _p(beta),
+                                                           _p(gamma), _p(out), B, H, W, Cin, Cout, act,
+                                                           _stream()), "conv_transpose2d_nhwc"))
     return out
 
 
@@ -123,8 +162,10 @@ def conv_transpose2d_image(x, w_packed, bias, Cimg, out=None):
     B, H, W, Cin = x.shape
     if out is None:
         out = torch.empty((B, Cimg, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().dsic_conv_transpose2d_image(_p(x), _p(w_packed), _p(bias), _p(out), B, H, W,
-                                                       Cin, Cimg, _stream()), "conv_transpose2d_image")
+    L = _lib.load()
+    _timed(_conv_kernel_name(3, 1, W, Cin, 32), 2.0 * B * H * W * Cimg * Cin * 25,
+           lambda: _lib.check(L.dsic_conv_transpose2d_image(_p(x), _p(w_packed), _p(bias), _p(out), B, H, W,
+                                                            Cin, Cimg, _stream()), "conv_transpose2d_image"))
     return out
 
 

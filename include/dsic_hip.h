@@ -146,6 +146,29 @@ int dsic_round(const float* x, float* out, int64_t n, void* stream);
 int dsic_gdn_nchw(const float* x, const float* beta, const float* gamma,
                   float* out, int B, int C, int HW, int inverse, void* stream);
 
+/* ---- distortion metrics -------------------------------------------------- */
+
+/* One MS-SSIM level (pytorch-msssim 1.0.0 semantics, called at
+ * modelseval.py:78-88, eval_selfcontained_entropy.py:154): 11-tap Gaussian
+ * "valid" filtering, cs/ssim maps, spatial means.  X,Y: [planes,H,W] (planes =
+ * B*C of an NCHW tensor); partial: workspace of dsic_ssim_partial_doubles()
+ * doubles; means: [planes][2] = (mean cs, mean ssim).  clamp_x clamps X to
+ * [0,1] on load (modelseval.py:178). */
+int64_t dsic_ssim_partial_doubles(int planes, int H, int W);
+int dsic_ssim_level(const float* X, const float* Y, double* partial,
+                    double* means, int planes, int H, int W, float C1, float C2,
+                    int clamp_x, void* stream);
+/* F.avg_pool2d(kernel=2, padding=size%2) between MS-SSIM levels. */
+int dsic_avgpool2(const float* src, float* dst, int planes, int H, int W,
+                  int clamp, void* stream);
+/* out[b] = mean_c prod_l relu(v_l)^w_l from means [levels][B*C][2]. */
+int dsic_msssim_finalize(const double* means, const float* weights, float* out,
+                         int levels, int B, int C, int relu_last, void* stream);
+/* out[b] = sum (a-b)^2 over one image (F.mse_loss numerator,
+ * modelseval.py:69-76); clamp_a clamps a to [0,1] first. */
+int dsic_sqerr_per_image(const float* a, const float* b, double* out, int B,
+                         int64_t n_per_image, int clamp_a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

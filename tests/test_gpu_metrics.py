@@ -1,0 +1,81 @@
+"""HIP metrics (MS-SSIM / SSIM / MSE) vs the oracle on the same inputs."""
+import numpy as np
+import pytest
+import torch
+
+from dsic_amd import synthetic as S
+from oracle import ref_metrics as RM
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(B, H, W, seed, C=3):
+    x = S.make_patches(seed, B, H, W, C)
+    noise = S.hash_uniform(x.size, 99, seed).reshape(x.shape) - 0.5
+    y = (0.8 * x + 0.1 + 0.2 * noise).astype(np.float32)     # leaves [0,1] in places
+    return torch.from_numpy(x), torch.from_numpy(y)
+
+
+@pytest.mark.parametrize("B,H,W,weights", [
+    (4, 256, 256, (0.3, 0.5, 0.2)),            # the reported metric (modelseval.py:80-85)
+    (2, 256, 256, None),                       # 5-scale default (eval_selfcontained_entropy.py:154)
+    (2, 176, 203, (0.3, 0.5, 0.2)),            # odd width: padded pooling
+    (1, 165, 163, None),
+])
+def test_ms_ssim_vs_oracle(B, H, W, weights):
+    from dsic_amd import metrics
+    x, y = _pair(B, H, W, 7)
+    want = RM.ms_ssim(y.clamp(0, 1), x, data_range=1.0, size_average=False, weights=weights).numpy()
+    got = metrics.ms_ssim(y.cuda(), x.cuda(), data_range=1.0, size_average=False, weights=weights,
+                          clamp_x=True).cpu().numpy()
+    # north_star tolerance: MS-SSIM within 1e-4 of the reference
+    assert np.max(np.abs(got - want)) < 1e-4, (got, want)
+    got2 = metrics.ms_ssim(y.clamp(0, 1).cuda(), x.cuda(), data_range=1.0, weights=weights).item()
+    assert abs(got2 - want.mean()) < 1e-4
+    if weights is not None:
+        mod = metrics.MS_SSIM(data_range=1.0, size_average=True, channel=3, weights=list(weights))
+        assert abs(mod(y.clamp(0, 1).cuda(), x.cuda()).item() - want.mean()) < 1e-4
+
+
+def test_small_image_asserts_then_ssim_fallback():
+    from dsic_amd import metrics
+    x, y = _pair(2, 120, 120, 2)
+    with pytest.raises(AssertionError):
+        metrics.MS_SSIM(data_range=1.0, weights=[0.3, 0.5, 0.2])(y.cuda(), x.cuda())
+    want = RM.ssim(y, x, data_range=1.0).item()
+    assert abs(metrics.ssim(y.cuda(), x.cuda(), data_range=1.0).item() - want) < 1e-4
+
+
+def test_identical_images_give_one():
+    from dsic_amd import metrics
+    x, _ = _pair(1, 192, 192, 5)
+    assert abs(metrics.ms_ssim(x.cuda(), x.cuda(), data_range=1.0).item() - 1.0) < 1e-5
+
+
+def test_mse_psnr():
+    from dsic_amd import metrics
+    x, y = _pair(3, 64, 80, 9)
+    assert abs(metrics.mse(y.cuda(), x.cuda()).item() - RM.compute_mse(y, x)) < 1e-8
+    per = metrics.mse_per_image(y.cuda(), x.cuda(), clamp_a=True).cpu().numpy()
+    want = ((y.clamp(0, 1) - x) ** 2).double().mean(dim=(1, 2, 3)).numpy()
+    np.testing.assert_allclose(per, want, rtol=1e-6)
+    assert abs(metrics.psnr_from_mse(per[0]) - RM.compute_psnr(y[:1].clamp(0, 1), x[:1])) < 1e-4
+
+
+def test_rate_distortion_loss_matches_oracle():
+    from dsic_amd.model import CompressionModel, rate_distortion_loss
+    from oracle import ref_model as O
+    sd = S.make_state_dict(seed=1)
+    m = CompressionModel(min_nu=2).cuda().eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    x = torch.from_numpy(S.make_patches(50, 1, 176, 176))
+    out = m(x.cuda(), "round")
+    ref = O.forward(sd, x, "round")
+    _, R, D = rate_distortion_loss(out, x.cuda(), 1.0, "mse")
+    assert abs(R.item() - O.rate_bpp(ref, 1, 176, 176).item()) < 1e-4
+    assert abs(D.item() - RM.compute_mse(ref["x_hat"], x)) < 1e-6
+    _, _, D2 = rate_distortion_loss(out, x.cuda(), 1.0, "msssim")
+    want = 1.0 - RM.ms_ssim(ref["x_hat"].clamp(0, 1), x, data_range=1.0, weights=(0.3, 0.5, 0.2)).item()
+    assert abs(D2.item() - want) < 1e-4
+    with pytest.raises(ValueError):
+        rate_distortion_loss(out, x.cuda(), 1.0, "psnr")
