@@ -1,0 +1,384 @@
+// Per-patch entropy coding on the GPU: support scan, CDF tables, range
+// encoder / decoder.  Restates the intent of
+// code/modelv2/eval_selfcontained_entropy.py:14-23 (gaussian_cdf,
+// pmf_to_uint16_cdf), :36-62 (per-image support, PMFs, z-then-y strings) and
+// :86-116 (decode), with the torchac 0.9.3 coder it calls (:48,62,96,116;
+// third-party: 32-bit low/high, 16-bit precision, pending-bit carry
+// resolution).  Interpretation choices are frozen in DESIGN.md "Entropy path".
+//
+// Parallel structure: tables are embarrassingly parallel (one wave per
+// (image, channel) table: 64 lanes evaluate the boundary CDFs in float64, lane 0
+// does the short sequential normalise/cumsum/quantise).  The coder's interval
+// update is a serial dependency chain per stream, so there is one workgroup
+// (one wave) per (image, stream): all 64 lanes translate a chunk of symbols to
+// (c_low, c_high) pairs in LDS, then lane 0 walks the chunk.  Matching leading
+// bits and pending (E3) runs are shifted out in bulk with clz instead of bit
+// by bit; the emitted bytes are identical to the bit-serial reference loop.
+// Integer work only after the tables: results are bit-exact by construction.
+#include "common.h"
+#include "dsic_math.h"
+
+namespace dsic {
+
+#define ENC_CHUNK 2048
+
+// meta[b] = {ymin - tail, Ly, zmin - tail, Lz}: :39-41, :52-54 (values are
+// integers already, so floor/ceil are the identity).
+__global__ __launch_bounds__(256) void support_kernel(const float* __restrict__ y,
+                                                      const float* __restrict__ z,
+                                                      int* __restrict__ meta, int64_t ny, int64_t nz,
+                                                      int tail) {
+  __shared__ float red[2][4];
+  const int b = blockIdx.x;
+  for (int which = 0; which < 2; ++which) {
+    const float* p = which ? z + (size_t)b * nz : y + (size_t)b * ny;
+    const int64_t n = which ? nz : ny;
+    float mn = p[0], mx = p[0];
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+      const float v = p[i];
+      mn = fminf(mn, v);
+      mx = fmaxf(mx, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mn = fminf(mn, __shfl_down(mn, o, 64));
+      mx = fmaxf(mx, __shfl_down(mx, o, 64));
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+      red[0][threadIdx.x >> 6] = mn;
+      red[1][threadIdx.x >> 6] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      mn = fminf(fminf(red[0][0], red[0][1]), fminf(red[0][2], red[0][3]));
+      mx = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+      const int lo = (int)floorf(mn) - tail, hi = (int)ceilf(mx) + tail;
+      meta[4 * b + 2 * which] = lo;
+      meta[4 * b + 2 * which + 1] = hi - lo + 1;
+    }
+  }
+}
+
+// One wave per table.  sigma/nu indexed [b*sb + c] (sb = 0 for the image-independent z prior).
+template <bool STUDENT>
+__global__ __launch_bounds__(256) void tables_kernel(const float* __restrict__ sigma,
+                                                     const float* __restrict__ nu, int sb,
+                                                     const int* __restrict__ meta, int meta_off,
+                                                     uint16_t* __restrict__ tables, int C, int Lmax,
+                                                     int ntables, int* __restrict__ err) {
+  extern __shared__ double shm[];  // per wave: F[Lmax+1], work[Lmax]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tid = blockIdx.x * 4 + wave;
+  if (tid >= ntables) return;
+  const int b = tid / C, c = tid % C;
+  const int smin = meta[4 * b + meta_off], L = meta[4 * b + meta_off + 1];
+  if (L > Lmax || L < 1) {
+    if (lane == 0) atomicOr(err, 1);
+    return;
+  }
+  double* F = shm + (size_t)wave * (2 * Lmax + 1);
+  double* work = F + Lmax + 1;
+  const double sg = (double)sigma[(size_t)b * sb + c];
+  const double nv = STUDENT ? (double)nu[(size_t)b * sb + c] : 0.0;
+  for (int k = lane; k <= L; k += 64) {
+    const double x = ((double)(smin + k) - 0.5) / sg;
+    F[k] = STUDENT ? dm::student_t_cdf(x, nv) : dm::normal_cdf(x);
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) dm::finish_table(F, L, tables + ((size_t)b * C + c) * Lmax, work);
+}
+
+struct BitSink {
+  uint32_t* out32;
+  uint8_t* out8;
+  int64_t cap, nbytes;
+  uint64_t acc;
+  int nbits;
+  int overflow;
+  __device__ __forceinline__ void put(uint32_t v, int len) {  // len in [0,32]
+    if (len == 0) return;
+    acc = (acc << len) | (uint64_t)v;
+    nbits += len;
+    if (nbits >= 32) {
+      const uint32_t w = (uint32_t)(acc >> (nbits - 32));
+      if (nbytes + 4 <= cap)
+        out32[nbytes >> 2] = __builtin_bswap32(w);
+      else
+        overflow = 1;
+      nbytes += 4;
+      nbits -= 32;
+    }
+  }
+  __device__ __forceinline__ void put_run(int bit, uint64_t count) {
+    while (count > 0) {
+      const int len = count > 32 ? 32 : (int)count;
+      put(bit ? (len == 32 ? 0xFFFFFFFFu : ((1u << len) - 1u)) : 0u, len);
+      count -= len;
+    }
+  }
+  __device__ __forceinline__ void finish() {  // whole bytes of the tail, zero padded
+    while (nbits > 0) {
+      const int take = nbits >= 8 ? 8 : nbits;
+      const uint32_t v = (uint32_t)((acc >> (nbits - take)) & ((1u << take) - 1u)) << (8 - take);
+      if (nbytes < cap)
+        out8[nbytes] = (uint8_t)v;
+      else
+        overflow = 1;
+      nbytes += 1;
+      nbits -= take;
+    }
+  }
+};
+
+// blockIdx.x = b*2 + which (0: z string, 1: y string), 64 threads.
+// sym: NCHW float latents (integer valued); pairs translated per chunk in LDS.
+__global__ __launch_bounds__(64) void range_encode_kernel(
+    const float* __restrict__ y, const float* __restrict__ z, const int* __restrict__ meta,
+    const uint16_t* __restrict__ tab_y, const uint16_t* __restrict__ tab_z, int Lmax, int M, int HWy,
+    int N, int HWz, uint8_t* __restrict__ out, int64_t cap_y, int64_t cap_z,
+    int* __restrict__ lengths, int* __restrict__ err) {
+  __shared__ uint32_t pairs[ENC_CHUNK];
+  const int b = blockIdx.x >> 1, which = blockIdx.x & 1;
+  const int C = which ? M : N, HW = which ? HWy : HWz;
+  const int64_t n = (int64_t)C * HW;
+  const float* sym = which ? y + (size_t)b * n : z + (size_t)b * n;
+  const uint16_t* tab = (which ? tab_y + (size_t)b * M * Lmax : tab_z + (size_t)b * N * Lmax);
+  const int smin = meta[4 * b + (which ? 0 : 2)], L = meta[4 * b + (which ? 1 : 3)];
+  const int64_t stride = cap_z + cap_y;  // per image: [z bytes | y bytes]
+  uint8_t* dst = out + (size_t)b * stride + (which ? cap_z : 0);
+  BitSink sink{(uint32_t*)dst, dst, which ? cap_y : cap_z, 0, 0, 0, 0};
+  uint32_t low = 0, high = 0xFFFFFFFFu;
+  uint64_t pending = 0;
+  int bad = (L > Lmax || L < 1);
+
+  for (int64_t base = 0; base < n && !bad; base += ENC_CHUNK) {
+    const int cnt = (int)((n - base) < ENC_CHUNK ? (n - base) : ENC_CHUNK);
+    for (int i = threadIdx.x; i < cnt; i += 64) {
+      const int64_t g = base + i;
+      const int c = (int)(g / HW);
+      const int s = (int)sym[g] - smin;
+      int sc = s;
+      if (s < 0 || s >= L) {  // cannot happen when meta came from dsic_latent_support on the same latents
+        atomicOr(err, 2);
+        sc = 0;
+      }
+      const uint16_t* t = tab + (size_t)c * Lmax;
+      const uint32_t c_low = t[sc];
+      const uint32_t c_high = (sc == L - 1) ? 0x10000u : (uint32_t)t[sc + 1];
+      const uint32_t pr = c_low | ((c_high - 1u) << 16);
+      pairs[i] = pr;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int i = 0; i < cnt; ++i) {
+        const uint32_t pr = pairs[i];
+        const uint64_t c_low = pr & 0xFFFFu, c_high = (uint64_t)(pr >> 16) + 1u;
+        const uint64_t span = (uint64_t)high - (uint64_t)low + 1u;
+        high = (low - 1u) + (uint32_t)((span * c_high) >> 16);
+        low = low + (uint32_t)((span * c_low) >> 16);
+        // E1/E2: n leading bits agree -> emit them (pending inverse bits after the first)
+        const uint32_t x = low ^ high;
+        const int nb = x ? __clz((int)x) : 32;
+        if (nb > 0) {
+          const uint32_t first = low >> 31;
+          sink.put(first, 1);
+          sink.put_run(first ? 0 : 1, pending);
+          pending = 0;
+          if (nb > 1) sink.put((low << 1) >> (33 - nb), nb - 1);
+          if (nb == 32) {
+            low = 0;
+            high = 0xFFFFFFFFu;
+          } else {
+            low <<= nb;
+            high = (high << nb) | ((1u << nb) - 1u);
+          }
+        }
+        // E3: low = 01.., high = 10..: m consecutive (1,0) pairs below the MSB
+        const uint32_t e3 = (low << 1) & ~(high << 1);
+        const int m = __clz((int)~e3);  // leading ones of e3 (<= 31 since bit 0 of e3 is 0)
+        if (m > 0) {
+          pending += (uint64_t)m;
+          low = (low << m) & 0x7FFFFFFFu;
+          high = (high << m) | 0x80000000u | ((1u << m) - 1u);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    pending += 1;
+    const uint32_t bit = low < 0x40000000u ? 0u : 1u;
+    sink.put(bit, 1);
+    sink.put_run(bit ? 0 : 1, pending);
+    sink.finish();
+    lengths[2 * b + which] = (int)sink.nbytes;
+    if (sink.overflow) atomicOr(err, 4);
+    if (bad) atomicOr(err, 1);
+  }
+}
+
+struct BitSource {
+  const uint8_t* in;
+  int64_t n, pos;
+  int bit;
+  __device__ __forceinline__ uint32_t get() {
+    if (pos >= n) return 0;
+    const uint32_t v = (in[pos] >> (7 - bit)) & 1u;
+    if (++bit == 8) {
+      bit = 0;
+      ++pos;
+    }
+    return v;
+  }
+};
+
+// One stream per block; lane 0 decodes.  in: [B] strings at stride `stride` bytes,
+// lengths[b*lstride + loff]; out: NCHW float latents (symbol + smin).
+__global__ __launch_bounds__(64) void range_decode_kernel(const uint8_t* __restrict__ in,
+                                                          int64_t stride,
+                                                          const int* __restrict__ lengths, int lstride,
+                                                          int loff, const int* __restrict__ meta,
+                                                          int meta_off,
+                                                          const uint16_t* __restrict__ tables, int Lmax,
+                                                          int C, int HW, float* __restrict__ out,
+                                                          int* __restrict__ err) {
+  extern __shared__ uint16_t stab[];  // this image's tables [C][L] when they fit
+  const int b = blockIdx.x;
+  const int smin = meta[4 * b + meta_off], L = meta[4 * b + meta_off + 1];
+  if (L > Lmax || L < 1) {
+    if (threadIdx.x == 0) atomicOr(err, 1);
+    return;
+  }
+  const uint16_t* gt = tables + (size_t)b * C * Lmax;
+  const bool in_lds = (size_t)C * L * 2 <= 48 * 1024;
+  if (in_lds) {
+    for (int i = threadIdx.x; i < C * L; i += 64) stab[i] = gt[(size_t)(i / L) * Lmax + (i % L)];
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  BitSource src{in + (size_t)b * stride, (int64_t)lengths[b * lstride + loff], 0, 0};
+  const int64_t n = (int64_t)C * HW;
+  float* dst = out + (size_t)b * n;
+  uint32_t low = 0, high = 0xFFFFFFFFu, value = 0;
+  for (int i = 0; i < 32; ++i) value = (value << 1) | src.get();
+  for (int64_t i = 0; i < n; ++i) {
+    const int c = (int)(i / HW);
+    const uint16_t* t = in_lds ? stab + (size_t)c * L : gt + (size_t)c * Lmax;
+    const uint64_t span = (uint64_t)high - (uint64_t)low + 1u;
+    const uint32_t count = (uint32_t)(((((uint64_t)value - (uint64_t)low + 1u) << 16) - 1u) / span);
+    int lo = 0, hi = L - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if ((uint32_t)t[mid] <= count)
+        lo = mid;
+      else
+        hi = mid - 1;
+    }
+    const int s = lo;
+    dst[i] = (float)(s + smin);
+    if (i == n - 1) break;
+    const uint64_t c_low = t[s];
+    const uint64_t c_high = (s == L - 1) ? 0x10000u : (uint64_t)t[s + 1];
+    high = (low - 1u) + (uint32_t)((span * c_high) >> 16);
+    low = low + (uint32_t)((span * c_low) >> 16);
+    for (;;) {
+      if (low >= 0x80000000u || high < 0x80000000u) {
+        low <<= 1;
+        high = (high << 1) | 1u;
+        value = (value << 1) | src.get();
+      } else if (low >= 0x40000000u && high < 0xC0000000u) {
+        low = (low << 1) & 0x7FFFFFFFu;
+        high = (high << 1) | 0x80000001u;
+        value -= 0x40000000u;
+        value = (value << 1) | src.get();
+      } else {
+        break;
+      }
+    }
+  }
+}
+
+}  // namespace dsic
+
+using namespace dsic;
+
+extern "C" int dsic_latent_support(const float* y_nchw, const float* z_nchw, int* meta, int B,
+                                   int64_t n_y, int64_t n_z, int tail, void* stream) {
+  DSIC_REQUIRE(y_nchw && z_nchw && meta, "latent_support: null pointer");
+  DSIC_REQUIRE(B > 0 && n_y > 0 && n_z > 0 && tail >= 0, "latent_support: bad argument");
+  hipLaunchKernelGGL(support_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, y_nchw, z_nchw, meta,
+                     n_y, n_z, tail);
+  return check_launch("latent_support");
+}
+
+static int tables_launch(bool student, const float* sigma, const float* nu, int per_image,
+                         const int* meta, int meta_off, uint16_t* tables, int B, int C, int Lmax,
+                         int* err, hipStream_t st) {
+  DSIC_REQUIRE(sigma && meta && tables && err && (!student || nu), "cdf_tables: null pointer");
+  DSIC_REQUIRE(B > 0 && C > 0 && Lmax >= 1 && Lmax <= 1000, "cdf_tables: Lmax=%d must be in [1,1000]", Lmax);
+  const int ntables = B * C;
+  const size_t shm = (size_t)4 * (2 * Lmax + 1) * sizeof(double);
+  const int sb = per_image ? C : 0;
+  if (student)
+    hipLaunchKernelGGL(tables_kernel<true>, dim3(ceil_div(ntables, 4)), dim3(256), shm, st, sigma, nu, sb,
+                       meta, meta_off, tables, C, Lmax, ntables, err);
+  else
+    hipLaunchKernelGGL(tables_kernel<false>, dim3(ceil_div(ntables, 4)), dim3(256), shm, st, sigma, nu, sb,
+                       meta, meta_off, tables, C, Lmax, ntables, err);
+  return check_launch("cdf_tables");
+}
+
+extern "C" int dsic_cdf_tables_gauss(const float* sigma_z, const int* meta, uint16_t* tables, int B,
+                                     int N, int Lmax, int* err, void* stream) {
+  return tables_launch(false, sigma_z, nullptr, 0, meta, 2, tables, B, N, Lmax, err, (hipStream_t)stream);
+}
+
+extern "C" int dsic_cdf_tables_student(const float* sigma, const float* nu, const int* meta,
+                                       uint16_t* tables, int B, int M, int Lmax, int* err,
+                                       void* stream) {
+  return tables_launch(true, sigma, nu, 1, meta, 0, tables, B, M, Lmax, err, (hipStream_t)stream);
+}
+
+extern "C" int dsic_range_encode(const float* y_nchw, const float* z_nchw, const int* meta,
+                                 const uint16_t* tab_y, const uint16_t* tab_z, int Lmax, int B, int M,
+                                 int HWy, int N, int HWz, uint8_t* out, int64_t cap_y, int64_t cap_z,
+                                 int* lengths, int* err, void* stream) {
+  DSIC_REQUIRE(y_nchw && z_nchw && meta && tab_y && tab_z && out && lengths && err,
+               "range_encode: null pointer");
+  DSIC_REQUIRE(B > 0 && M > 0 && N > 0 && HWy > 0 && HWz > 0, "range_encode: empty latent");
+  DSIC_REQUIRE(cap_y % 4 == 0 && cap_z % 4 == 0 && cap_y >= 8 && cap_z >= 8,
+               "range_encode: capacities must be multiples of 4 and >= 8");
+  hipLaunchKernelGGL(range_encode_kernel, dim3(2 * B), dim3(64), 0, (hipStream_t)stream, y_nchw, z_nchw,
+                     meta, tab_y, tab_z, Lmax, M, HWy, N, HWz, out, cap_y, cap_z, lengths, err);
+  return check_launch("range_encode");
+}
+
+extern "C" int dsic_range_decode(const uint8_t* in, int64_t stride, const int* lengths, int lstride,
+                                 int loff, const int* meta, int meta_off, const uint16_t* tables,
+                                 int Lmax, int B, int C, int HW, float* out_nchw, int* err,
+                                 void* stream) {
+  DSIC_REQUIRE(in && lengths && meta && tables && out_nchw && err, "range_decode: null pointer");
+  DSIC_REQUIRE(B > 0 && C > 0 && HW > 0 && Lmax >= 1, "range_decode: bad argument");
+  DSIC_REQUIRE(meta_off == 0 || meta_off == 2, "range_decode: meta_off must be 0 (y) or 2 (z)");
+  hipLaunchKernelGGL(range_decode_kernel, dim3(B), dim3(64), 48 * 1024, (hipStream_t)stream, in, stride,
+                     lengths, lstride, loff, meta, meta_off, tables, Lmax, C, HW, out_nchw, err);
+  return check_launch("range_decode");
+}
+
+// Host-side evaluation of the same table math (CPU tests compare it with the
+// oracle without a GPU; the device kernels are compared on the GPU box).
+extern "C" double dsic_host_normal_cdf(double x) { return dm::normal_cdf(x); }
+extern "C" double dsic_host_student_t_cdf(double t, double nu) { return dm::student_t_cdf(t, nu); }
+extern "C" int dsic_host_cdf_table(int student, float sigma, float nu, int smin, int L,
+                                   uint16_t* out_host) {
+  DSIC_REQUIRE(out_host && L >= 1 && L <= 4096, "host_cdf_table: bad argument");
+  double F[4097], work[4096];
+  for (int k = 0; k <= L; ++k) {
+    const double x = ((double)(smin + k) - 0.5) / (double)sigma;
+    F[k] = student ? dm::student_t_cdf(x, (double)nu) : dm::normal_cdf(x);
+  }
+  dm::finish_table(F, L, out_host, work);
+  return DSIC_OK;
+}

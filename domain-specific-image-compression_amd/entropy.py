@@ -1,0 +1,191 @@
+"""Mirror of code/modelv2/eval_selfcontained_entropy.py: custom_compress /
+custom_decompress / evaluate-style helpers, running on the GPU.
+
+The reference script is a sketch that cannot execute (StudentT.cdf is not
+implemented in torch; torchac is called with arguments it does not accept —
+SURVEY.md §8c).  This module keeps its interface — the returned dict of :68-74,
+`tail=10`, z string then y string per image, decode order of :76-123 — and the
+interpretation frozen in DESIGN.md "Entropy path".
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from . import ops
+from .ops import _f32c, _p, _stream
+
+DEFAULT_LMAX = 256
+
+
+class EntropyError(RuntimeError):
+    pass
+
+
+def _check_err(err, what):
+    code = int(err.item())
+    if code:
+        reasons = [m for bit, m in ((1, "support wider than Lmax"), (2, "symbol outside its support"),
+                                    (4, "output capacity exceeded")) if code & bit]
+        raise EntropyError(f"{what}: " + ", ".join(reasons))
+
+
+def gaussian_cdf(x):
+    """:14-15, float64 on the host through the library's own table math."""
+    L = _lib.load()
+    a = np.asarray(x, dtype=np.float64)
+    return np.array([L.dsic_host_normal_cdf(float(v)) for v in a.ravel()]).reshape(a.shape)
+
+
+def latent_support(y_tilde, z_tilde, tail=10):
+    """-> meta int32 [B,4] = (ymin-tail, Ly, zmin-tail, Lz) on the device (:39-41, :52-54)."""
+    y = _f32c(y_tilde, "latent_support")
+    z = _f32c(z_tilde, "latent_support")
+    B = y.shape[0]
+    meta = torch.empty((B, 4), dtype=torch.int32, device=y.device)
+    _lib.check(_lib.load().dsic_latent_support(_p(y), _p(z), _p(meta), B, y[0].numel(), z[0].numel(), int(tail),
+                                               _stream()), "latent_support")
+    return meta
+
+
+def cdf_tables(sigma_y, nu_y, sigma_z, meta, Lmax=DEFAULT_LMAX, err=None):
+    """-> (tab_y [B,M,Lmax], tab_z [B,N,Lmax]) uint16 coder tables (:43-47, :55-61, :17-23)."""
+    sy = _f32c(sigma_y, "cdf_tables")
+    ny = _f32c(nu_y, "cdf_tables")
+    sz = _f32c(sigma_z, "cdf_tables")
+    B, M = sy.shape
+    N = sz.numel()
+    dev = sy.device
+    if err is None:
+        err = torch.zeros(1, dtype=torch.int32, device=dev)
+    tab_y = torch.zeros((B, M, Lmax), dtype=torch.uint16, device=dev)
+    tab_z = torch.zeros((B, N, Lmax), dtype=torch.uint16, device=dev)
+    L = _lib.load()
+    _lib.check(L.dsic_cdf_tables_gauss(_p(sz), _p(meta), _p(tab_z), B, N, Lmax, _p(err), _stream()),
+               "cdf_tables_gauss")
+    _lib.check(L.dsic_cdf_tables_student(_p(sy), _p(ny), _p(meta), _p(tab_y), B, M, Lmax, _p(err), _stream()),
+               "cdf_tables_student")
+    return tab_y, tab_z, err
+
+
+def _cap(n):
+    return (2 * n + 16 + 3) // 4 * 4   # <= 16 bits per symbol + flush, multiple of 4
+
+
+@torch.no_grad()
+def compress_latents(y_tilde, z_tilde, sigma_y, nu_y, sigma_z, tail=10, Lmax=DEFAULT_LMAX):
+    """Device-resident compress of already computed latents.
+
+    y_tilde [B,M,Hy,Wy], z_tilde [B,N,Hz,Wz] integer-valued (quant_mode="round");
+    sigma_y/nu_y [B,M]; sigma_z [N].  Returns dict with device tensors:
+    bytes uint8 [B, cap_z+cap_y], lengths int32 [B,2] (z,y), meta int32 [B,4],
+    cap_z, cap_y, tab_y, tab_z, err.  Nothing synchronises with the host.
+    """
+    y = _f32c(y_tilde, "compress")
+    z = _f32c(z_tilde, "compress")
+    B, M, Hy, Wy = y.shape
+    _, N, Hz, Wz = z.shape
+    dev = y.device
+    meta = latent_support(y, z, tail)
+    tab_y, tab_z, err = cdf_tables(sigma_y, nu_y, sigma_z, meta, Lmax)
+    cap_y, cap_z = _cap(M * Hy * Wy), _cap(N * Hz * Wz)
+    out = torch.empty((B, cap_z + cap_y), dtype=torch.uint8, device=dev)
+    lengths = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().dsic_range_encode(_p(y), _p(z), _p(meta), _p(tab_y), _p(tab_z), Lmax, B, M, Hy * Wy,
+                                             N, Hz * Wz, _p(out), cap_y, cap_z, _p(lengths), _p(err),
+                                             _stream()), "range_encode")
+    return {"bytes": out, "lengths": lengths, "meta": meta, "cap_z": cap_z, "cap_y": cap_y,
+            "tab_y": tab_y, "tab_z": tab_z, "err": err, "shape_y": list(y.shape), "shape_z": list(z.shape)}
+
+
+def _per_channel(t):
+    """[B,M,H,W] spatially constant (expanded) or [B,M] -> contiguous [B,M]."""
+    return (t[:, :, 0, 0] if t.dim() == 4 else t).contiguous()
+
+
+@torch.no_grad()
+def custom_compress(model, x, tail=10, Lmax=DEFAULT_LMAX):
+    """eval_selfcontained_entropy.py:26-74.  Returns the reference's dict:
+    strings [[z_bytes, y_bytes], ...], shape_y, shape_z, min_y, max_y, min_z, max_z."""
+    out = model(x, quant_mode="round")
+    sigma_z = torch.exp(model.z_prior.log_sigma)                       # :32 (no clamp)
+    while True:
+        c = compress_latents(out["y_tilde"], out["z_tilde"], _per_channel(out["sigma"]),
+                             _per_channel(out["nu"]), sigma_z, tail, Lmax)
+        try:
+            _check_err(c["err"], "custom_compress")
+            break
+        except EntropyError:
+            if Lmax >= 1000 or not (int(c["err"].item()) & 1):
+                raise
+            Lmax = min(1000, Lmax * 2)                                 # wider support than expected
+    lengths = c["lengths"].cpu().numpy()
+    meta = c["meta"].cpu().numpy()
+    raw = c["bytes"].cpu().numpy()
+    strings = []
+    for b in range(raw.shape[0]):
+        zs = raw[b, :lengths[b, 0]].tobytes()
+        ys = raw[b, c["cap_z"]:c["cap_z"] + lengths[b, 1]].tobytes()
+        strings.append([zs, ys])
+    return {
+        "strings": strings,
+        "shape_y": c["shape_y"], "shape_z": c["shape_z"],
+        "min_y": [int(m[0]) for m in meta], "max_y": [int(m[0] + m[1] - 1) for m in meta],
+        "min_z": [int(m[2]) for m in meta], "max_z": [int(m[2] + m[3] - 1) for m in meta],
+    }
+
+
+def _upload_strings(strings, which, dev):
+    lens = [len(s[which]) for s in strings]
+    stride = max(4, (max(lens) + 3) // 4 * 4)
+    buf = np.zeros((len(strings), stride), dtype=np.uint8)
+    for b, s in enumerate(strings):
+        buf[b, :lens[b]] = np.frombuffer(s[which], dtype=np.uint8)
+    return (torch.from_numpy(buf).to(dev), torch.tensor(lens, dtype=torch.int32, device=dev), stride)
+
+
+@torch.no_grad()
+def custom_decompress(model, compressed, Lmax=None):
+    """eval_selfcontained_entropy.py:76-123: decode z, re-run h_s, decode y, run g_s, clamp."""
+    dev = next(model.parameters()).device
+    strings = compressed["strings"]
+    B = len(strings)
+    _, M, Hy, Wy = compressed["shape_y"]
+    _, N, Hz, Wz = compressed["shape_z"]
+    meta_np = np.array([[compressed["min_y"][b], compressed["max_y"][b] - compressed["min_y"][b] + 1,
+                         compressed["min_z"][b], compressed["max_z"][b] - compressed["min_z"][b] + 1]
+                        for b in range(B)], dtype=np.int32)
+    if Lmax is None:
+        Lmax = max(DEFAULT_LMAX, int(meta_np[:, [1, 3]].max()))
+    meta = torch.from_numpy(meta_np).to(dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    L = _lib.load()
+    sigma_z = torch.exp(model.z_prior.log_sigma).contiguous()
+    tab_z = torch.zeros((B, N, Lmax), dtype=torch.uint16, device=dev)
+    _lib.check(L.dsic_cdf_tables_gauss(_p(sigma_z), _p(meta), _p(tab_z), B, N, Lmax, _p(err), _stream()),
+               "cdf_tables_gauss")
+    zbuf, zlen, zstride = _upload_strings(strings, 0, dev)
+    z_hat = torch.empty((B, N, Hz, Wz), dtype=torch.float32, device=dev)
+    _lib.check(L.dsic_range_decode(_p(zbuf), zstride, _p(zlen), 1, 0, _p(meta), 2, _p(tab_z), Lmax, B, N,
+                                   Hz * Wz, _p(z_hat), _p(err), _stream()), "range_decode(z)")
+    # :100-106: hyper-synthesis on the decoded z
+    (_, _, sigma_y, nu_y), _ = model.h_s.params_nhwc(ops.nchw_to_nhwc(z_hat), model.min_nu, model.max_nu)
+    tab_y = torch.zeros((B, M, Lmax), dtype=torch.uint16, device=dev)
+    _lib.check(L.dsic_cdf_tables_student(_p(sigma_y), _p(nu_y), _p(meta), _p(tab_y), B, M, Lmax, _p(err),
+                                         _stream()), "cdf_tables_student")
+    ybuf, ylen, ystride = _upload_strings(strings, 1, dev)
+    y_hat = torch.empty((B, M, Hy, Wy), dtype=torch.float32, device=dev)
+    _lib.check(L.dsic_range_decode(_p(ybuf), ystride, _p(ylen), 1, 0, _p(meta), 0, _p(tab_y), Lmax, B, M,
+                                   Hy * Wy, _p(y_hat), _p(err), _stream()), "range_decode(y)")
+    _check_err(err, "custom_decompress")
+    x_hat = model.g_s.forward_nhwc(ops.nchw_to_nhwc(y_hat))            # :120
+    return x_hat.clamp(0, 1)                                           # :123
+
+
+def real_bpp(compressed, H, W):
+    """:148-149 — 8 * total bytes / (H*W), per batch."""
+    total_bits = sum(len(s) * 8 for entry in compressed["strings"] for s in entry)
+    return total_bits / float(H * W)

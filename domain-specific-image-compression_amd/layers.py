@@ -42,10 +42,17 @@ class GDN(nn.Module):
         self.gamma_conv = _GammaConv(channels, gamma.diag())
 
     def effective(self):
-        """(beta_eff, gamma_eff) = (beta^2 - off, w^2 - off), layers.py:20-21."""
-        beta = self.beta ** 2 - self.reparam_offset
-        gamma = (self.gamma_conv.weight ** 2 - self.reparam_offset).reshape(-1)
-        return beta.contiguous(), gamma.contiguous()
+        """(beta_eff, gamma_eff) = (beta^2 - off, w^2 - off), layers.py:20-21.
+
+        Cached until a parameter is rewritten or moved (load_state_dict, .to())."""
+        w = self.gamma_conv.weight
+        key = (self.beta._version, self.beta.data_ptr(), w._version, w.data_ptr())
+        if getattr(self, "_eff_key", None) != key:
+            beta = self.beta ** 2 - self.reparam_offset
+            gamma = (w ** 2 - self.reparam_offset).reshape(-1)
+            self._eff = (beta.contiguous(), gamma.contiguous())
+            self._eff_key = key
+        return self._eff
 
     @torch.no_grad()
     def forward(self, x):

@@ -46,6 +46,16 @@ SIGNATURES = {
     "dsic_avgpool2": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "dsic_msssim_finalize": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "dsic_sqerr_per_image": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P]),
+    "dsic_latent_support": (c_int, [_P, _P, _P, c_int, c_int64, c_int64, c_int, _P]),
+    "dsic_cdf_tables_gauss": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P]),
+    "dsic_cdf_tables_student": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P]),
+    "dsic_range_encode": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P,
+                                  c_int64, c_int64, _P, _P, _P]),
+    "dsic_range_decode": (c_int, [_P, c_int64, _P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int,
+                                  c_int, _P, _P, _P]),
+    "dsic_host_normal_cdf": (ctypes.c_double, [ctypes.c_double]),
+    "dsic_host_student_t_cdf": (ctypes.c_double, [ctypes.c_double, ctypes.c_double]),
+    "dsic_host_cdf_table": (c_int, [c_int, ctypes.c_float, ctypes.c_float, c_int, c_int, _P]),
 }
 
 _lib = None

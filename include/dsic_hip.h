@@ -169,6 +169,54 @@ int dsic_msssim_finalize(const double* means, const float* weights, float* out,
 int dsic_sqerr_per_image(const float* a, const float* b, double* out, int B,
                          int64_t n_per_image, int clamp_a, void* stream);
 
+/* ---- per-patch entropy coding ------------------------------------------- */
+/* Restates custom_compress / custom_decompress of
+ * code/modelv2/eval_selfcontained_entropy.py:26-123 and the torchac 0.9.3
+ * calls inside them (third-party; :48,62,96,116).  The script cannot execute
+ * as written; the frozen interpretation is in DESIGN.md.
+ * err: device int, OR-ed with 1 (support wider than Lmax), 2 (symbol outside
+ * its support), 4 (output capacity exceeded); callers zero it first. */
+
+/* :39-41,52-54: meta[b] = {min(y)-tail, Ly, min(z)-tail, Lz}, L = max-min+2*tail+1.
+ * y_nchw/z_nchw: integer-valued float latents (y_tilde, z_tilde), n_* per image. */
+int dsic_latent_support(const float* y_nchw, const float* z_nchw, int* meta,
+                        int B, int64_t n_y, int64_t n_z, int tail, void* stream);
+
+/* :43-47 gaussian PMF -> pmf_to_uint16_cdf (:17-23) -> spread table.
+ * sigma_z [N] = exp(z_prior.log_sigma) (:32, no clamp); tables [B][N][Lmax]
+ * uint16, entry k = c[k] for k < L_b (c[L_b] = 65536 implicit). */
+int dsic_cdf_tables_gauss(const float* sigma_z, const int* meta,
+                          uint16_t* tables, int B, int N, int Lmax, int* err,
+                          void* stream);
+/* :55-61 Student-t PMF tables; sigma, nu [B][M] (spatially constant). */
+int dsic_cdf_tables_student(const float* sigma, const float* nu,
+                            const int* meta, uint16_t* tables, int B, int M,
+                            int Lmax, int* err, void* stream);
+
+/* torchac.encode_float_cdf call sites :48,62: per image the z string then the
+ * y string.  out: [B][cap_z + cap_y] bytes (z at offset 0, y at cap_z),
+ * lengths [B][2] = {len_z, len_y}.  Symbol order C,H,W of the NCHW latents. */
+int dsic_range_encode(const float* y_nchw, const float* z_nchw, const int* meta,
+                      const uint16_t* tab_y, const uint16_t* tab_z, int Lmax,
+                      int B, int M, int HWy, int N, int HWz, uint8_t* out,
+                      int64_t cap_y, int64_t cap_z, int* lengths, int* err,
+                      void* stream);
+
+/* torchac.decode_float_cdf call sites :96,116: string b starts at
+ * in + b*stride and has lengths[b*lstride + loff] bytes; meta_off 0 = y, 2 = z.
+ * out: NCHW float latents [B][C][HW] (symbol + min). */
+int dsic_range_decode(const uint8_t* in, int64_t stride, const int* lengths,
+                      int lstride, int loff, const int* meta, int meta_off,
+                      const uint16_t* tables, int Lmax, int B, int C, int HW,
+                      float* out_nchw, int* err, void* stream);
+
+/* The table math evaluated on the HOST (no GPU needed): lets CPU-only tests
+ * compare it bit for bit with the oracle.  out_host: L uint16 in host memory. */
+double dsic_host_normal_cdf(double x);
+double dsic_host_student_t_cdf(double t, double nu);
+int dsic_host_cdf_table(int student, float sigma, float nu, int smin, int L,
+                        uint16_t* out_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,120 @@
+"""GPU entropy path (tables, range encoder/decoder) vs the oracle: bit-exact on the same inputs."""
+import numpy as np
+import pytest
+import torch
+
+from dsic_amd import synthetic as S
+from oracle import entropy_ref as E
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model():
+    from dsic_amd.model import CompressionModel
+    sd = S.make_state_dict(seed=1)
+    m = CompressionModel(N=128, M=192, spatial_params=False, min_nu=2, max_nu=100.0)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return m.cuda().eval()
+
+
+def _oracle_inputs(out, model):
+    y = out["y_tilde"].cpu().numpy()
+    z = out["z_tilde"].cpu().numpy()
+    sy = out["sigma"][:, :, 0, 0].cpu().numpy()
+    ny = out["nu"][:, :, 0, 0].cpu().numpy()
+    sz = torch.exp(model.z_prior.log_sigma).cpu().numpy()
+    return y, z, sy, ny, sz
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 128, 96), (1, 256, 256), (3, 48, 80)])
+def test_custom_compress_is_bit_exact_to_oracle(model, B, H, W):
+    from dsic_amd import entropy
+    x = torch.from_numpy(S.make_patches(200, B, H, W)).cuda()
+    out = model(x, quant_mode="round")
+    y, z, sy, ny, sz = _oracle_inputs(out, model)
+    want = E.compress(y, z, sy, ny, sz, tail=10)
+    got = entropy.custom_compress(model, x, tail=10)
+    assert set(got) == {"strings", "shape_y", "shape_z", "min_y", "max_y", "min_z", "max_z"}
+    for k in ("shape_y", "shape_z", "min_y", "max_y", "min_z", "max_z"):
+        assert got[k] == want[k], k
+    for b in range(B):
+        assert got["strings"][b][0] == want["strings"][b][0], f"z string of image {b}"
+        assert got["strings"][b][1] == want["strings"][b][1], f"y string of image {b}"
+    # the coded size tracks the density estimate (model.py:76) from above, within a few percent
+    est_bits = float(out.sums.sum().item())
+    real_bits = 8 * sum(len(s) for e in got["strings"] for s in e)
+    assert 0.98 * est_bits < real_bits < 1.10 * est_bits + 64 * B, (est_bits, real_bits)
+    assert abs(entropy.real_bpp(got, H, W) - real_bits / (H * W)) < 1e-12
+    # decode on the GPU: identical latents -> identical reconstruction
+    x_hat = entropy.custom_decompress(model, got)
+    assert torch.equal(x_hat, out["x_hat"].clamp(0, 1))
+    # and the oracle decodes the GPU's strings
+    for b in range(B):
+        assert np.array_equal(E.decode_z(got, b, sz), z[b])
+        assert np.array_equal(E.decode_y(got, b, sy[b], ny[b]), y[b])
+
+
+def test_device_tables_equal_oracle(model):
+    from dsic_amd import entropy
+    x = torch.from_numpy(S.make_patches(300, 2, 64, 64)).cuda()
+    out = model(x, quant_mode="round")
+    y, z, sy, ny, sz = _oracle_inputs(out, model)
+    meta = entropy.latent_support(out["y_tilde"], out["z_tilde"], 10)
+    m = meta.cpu().numpy()
+    for b in range(2):
+        assert m[b, 0] == int(y[b].min()) - 10 and m[b, 1] == int(y[b].max() - y[b].min()) + 21
+        assert m[b, 2] == int(z[b].min()) - 10 and m[b, 3] == int(z[b].max() - z[b].min()) + 21
+    tab_y, tab_z, err = entropy.cdf_tables(out["sigma"][:, :, 0, 0].contiguous(), out["nu"][:, :, 0, 0].contiguous(),
+                                           torch.exp(model.z_prior.log_sigma), meta, 128)
+    assert int(err.item()) == 0
+    ty, tz = tab_y.cpu().numpy(), tab_z.cpu().numpy()
+    for b in range(2):
+        Ly, Lz = int(m[b, 1]), int(m[b, 3])
+        assert np.array_equal(ty[b, :, :Ly], E.tables_student(sy[b], ny[b], int(m[b, 0]), Ly))
+        assert np.array_equal(tz[b, :, :Lz], E.tables_gauss(sz, int(m[b, 2]), Lz))
+
+
+@pytest.mark.parametrize("case", ["random", "peaky", "runs", "single"])
+def test_range_coder_stress_vs_oracle(case):
+    """Synthetic latents that exercise long pending runs, one-count intervals and tiny streams."""
+    from dsic_amd import entropy
+    rng = np.random.default_rng(11)
+    B, M, N, Hy, Wy, Hz, Wz = 3, 16, 8, 8, 12, 2, 3
+    if case == "single":
+        B, M, N, Hy, Wy, Hz, Wz = 2, 1, 1, 1, 1, 1, 1
+    if case == "random":
+        y = np.rint(rng.standard_t(2.5, size=(B, M, Hy, Wy)) * 3).clip(-60, 60)
+        sy = rng.uniform(0.5, 6.0, (B, M)); ny = rng.uniform(2.0, 50.0, (B, M))
+    elif case == "peaky":   # sigma tiny: almost all mass in one bin, other symbols sit on 1-count intervals
+        y = np.zeros((B, M, Hy, Wy)); y[:, :, ::3, ::5] = rng.integers(-9, 10, size=y[:, :, ::3, ::5].shape)
+        sy = np.full((B, M), 1e-3); ny = np.full((B, M), 2.0)
+    elif case == "runs":    # symmetric two-valued stream around the interval midpoint -> pending runs
+        y = np.where(rng.random((B, M, Hy, Wy)) < 0.5, 0.0, -1.0)
+        sy = np.full((B, M), 40.0); ny = np.full((B, M), 100.0)
+    else:
+        y = np.array([3.0, -2.0]).reshape(B, 1, 1, 1)
+        sy = np.full((B, M), 1.0); ny = np.full((B, M), 5.0)
+    z = np.rint(rng.normal(size=(B, N, Hz, Wz)) * 4)
+    sz = rng.uniform(0.5, 5.0, N)
+    y, z = y.astype(np.float32), z.astype(np.float32)
+    sy, ny, sz = sy.astype(np.float32), ny.astype(np.float32), sz.astype(np.float32)
+    want = E.compress(y, z, sy, ny, sz, tail=10)
+    c = entropy.compress_latents(torch.from_numpy(y).cuda(), torch.from_numpy(z).cuda(), torch.from_numpy(sy).cuda(),
+                                 torch.from_numpy(ny).cuda(), torch.from_numpy(sz).cuda(), tail=10, Lmax=192)
+    assert int(c["err"].item()) == 0
+    lens = c["lengths"].cpu().numpy()
+    raw = c["bytes"].cpu().numpy()
+    for b in range(B):
+        assert raw[b, :lens[b, 0]].tobytes() == want["strings"][b][0]
+        assert raw[b, c["cap_z"]:c["cap_z"] + lens[b, 1]].tobytes() == want["strings"][b][1]
+
+
+def test_errors_are_reported(model):
+    from dsic_amd import entropy
+    y = torch.zeros((1, 4, 2, 2), device="cuda"); y[0, 0, 0, 0] = 500.0
+    z = torch.zeros((1, 2, 1, 1), device="cuda")
+    c = entropy.compress_latents(y, z, torch.ones((1, 4), device="cuda"), torch.full((1, 4), 3.0, device="cuda"),
+                                 torch.ones(2, device="cuda"), tail=10, Lmax=64)
+    with pytest.raises(entropy.EntropyError):
+        entropy._check_err(c["err"], "test")
