@@ -86,7 +86,13 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--channels", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--coder-cus", type=int, default=0,
+                    help="CUs reserved for the range coder's stream (0 = no CU masking)")
+    ap.add_argument("--entropy", action="store_true",
+                    help="BASELINE config 3: also build the CDF tables and range-code the z,y strings on the "
+                         "GPU (second stream); default is config 2 (transforms + rate + metrics)")
     args = ap.parse_args()
+    args.no_entropy = not args.entropy
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -102,7 +108,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
 
-    from dsic_amd import metrics, ops, synthetic as S
+    from dsic_amd import entropy, metrics, ops, synthetic as S
     from dsic_amd.model import CompressionModel
 
     B, H, W, C = args.batch, args.size, args.size, args.channels
@@ -116,16 +122,40 @@ def main():
 
     timer = KernelTimer()
     ops.set_kernel_timer(timer)
-    totals = torch.zeros(3, dtype=torch.float64, device=dev)
+    totals = torch.zeros(4, dtype=torch.float64, device=dev)
+    coder = None
+    main_stream = torch.cuda.current_stream()
+    if not args.no_entropy:
+        if args.coder_cus > 0:
+            # the serial coder owns a few CUs (8 streams per CU); conv kernels use the others
+            main_stream, side = entropy.masked_streams(args.coder_cus)
+            coder = entropy.AsyncCompressor(model, stream=side, streams_per_wg=8)
+        else:
+            coder = entropy.AsyncCompressor(model)
+    torch.cuda.set_stream(main_stream)
+    count = torch.tensor(float(B), dtype=torch.float64, device=dev)
+    zero = torch.zeros((), dtype=torch.float64, device=dev)
+
+    pending = []
 
     def step():
-        out = model(x, quant_mode="round")
+        # range coder of this batch runs on a second stream beside synthesis + MS-SSIM
+        out = model(x, quant_mode="round", after_rate=coder)
         bpp = out.sums.sum(dim=1) / float(H * W)                 # per image (modelseval.py:90-94)
         msssim = metrics.ms_ssim_per_image(out["x_hat"], x, clamp_x=True)
-        t = torch.stack([bpp.sum(), msssim.double().sum(),
-                         torch.tensor(float(B), dtype=torch.float64, device=dev)])
+        real = zero
+        if coder is not None:
+            # the strings of THIS step are still being coded beside synthesis; the coded size
+            # that enters this step's reduction is the previous step's (same batch), joined at
+            # stream level without a host sync.  The last step is joined before the clock stops.
+            prev = pending.pop() if pending else None
+            pending.append(coder.last)
+            if prev is not None:
+                torch.cuda.current_stream().wait_event(prev["done"])
+                real = prev["lengths"].sum().double() * 8.0 / float(H * W)   # eval_selfcontained_entropy.py:148-149
+        t = torch.stack([bpp.sum(), msssim.double().sum(), count, real])
         if world > 1:
-            dist.all_reduce(t)                                   # the one collective: 3 x fp64
+            dist.all_reduce(t)                                   # the one collective: 4 x fp64
         totals.copy_(t)
         return out
 
@@ -142,6 +172,9 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if coder is not None:
+        last = coder.wait()
+        totals[3] = last["lengths"].sum().double() * 8.0 / float(H * W) * (world if world > 1 else 1)
     barrier()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
@@ -179,13 +212,16 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"batch={B}/GPU {H}x{W}x{C} synthetic patches, modelv2 encode->decode "
-                            "(g_a,h_a,round,h_s,Student-t/Gaussian rate,g_s) + bpp + MS-SSIM[.3,.5,.2] on GPU",
+                            "(g_a,h_a,round,h_s,Student-t/Gaussian rate,g_s) + bpp + MS-SSIM[.3,.5,.2] on GPU"
+                            + (" [BASELINE config 2]" if args.no_entropy else
+                               " + CDF tables and range coder (z,y strings) on GPU [BASELINE config 3]"),
                 "global_batch": B * world,
-                "parallelism": f"per-image sharding x{world}, one all-reduce of 3 fp64",
+                "parallelism": f"per-image sharding x{world}, one all-reduce of 4 fp64",
                 "weights": "synthetic seed 1 (checkpoints absent from the reference)",
             },
             "mean_bpp": float(tot[0] / n_img),
             "mean_ms_ssim": float(tot[1] / n_img),
+            "mean_bpp_coded": (float(tot[3] / n_img) if not args.no_entropy else None),
             "images_per_s_per_gpu": value / world,
             "roofline": {
                 "bound": "mfma",

@@ -20,8 +20,6 @@
 
 namespace dsic {
 
-#define ENC_CHUNK 2048
-
 // meta[b] = {ymin - tail, Ly, zmin - tail, Lz}: :39-41, :52-54 (values are
 // integers already, so floor/ceil are the identity).
 __global__ __launch_bounds__(256) void support_kernel(const float* __restrict__ y,
@@ -90,57 +88,22 @@ __global__ __launch_bounds__(256) void tables_kernel(const float* __restrict__ s
   if (lane == 0) dm::finish_table(F, L, tables + ((size_t)b * C + c) * Lmax, work);
 }
 
-struct BitSink {
-  uint32_t* out32;
-  uint8_t* out8;
-  int64_t cap, nbytes;
-  uint64_t acc;
-  int nbits;
-  int overflow;
-  __device__ __forceinline__ void put(uint32_t v, int len) {  // len in [0,32]
-    if (len == 0) return;
-    acc = (acc << len) | (uint64_t)v;
-    nbits += len;
-    if (nbits >= 32) {
-      const uint32_t w = (uint32_t)(acc >> (nbits - 32));
-      if (nbytes + 4 <= cap)
-        out32[nbytes >> 2] = __builtin_bswap32(w);
-      else
-        overflow = 1;
-      nbytes += 4;
-      nbits -= 32;
-    }
-  }
-  __device__ __forceinline__ void put_run(int bit, uint64_t count) {
-    while (count > 0) {
-      const int len = count > 32 ? 32 : (int)count;
-      put(bit ? (len == 32 ? 0xFFFFFFFFu : ((1u << len) - 1u)) : 0u, len);
-      count -= len;
-    }
-  }
-  __device__ __forceinline__ void finish() {  // whole bytes of the tail, zero padded
-    while (nbits > 0) {
-      const int take = nbits >= 8 ? 8 : nbits;
-      const uint32_t v = (uint32_t)((acc >> (nbits - take)) & ((1u << take) - 1u)) << (8 - take);
-      if (nbytes < cap)
-        out8[nbytes] = (uint8_t)v;
-      else
-        overflow = 1;
-      nbytes += 1;
-      nbits -= take;
-    }
-  }
-};
-
-// blockIdx.x = b*2 + which (0: z string, 1: y string), 64 threads.
-// sym: NCHW float latents (integer valued); pairs translated per chunk in LDS.
-__global__ __launch_bounds__(64) void range_encode_kernel(
+// Range encoder, one wave per (image, stream): stream id = b*2 + which (0: z
+// string, 1: y string); four streams (one per SIMD) share a workgroup so that a
+// batch occupies few CUs and leaves the rest to concurrently running conv kernels.  Each lane translates one symbol of a 64-symbol group to
+// its (c_low, c_high-1) pair (table gather, prefetched one group ahead); the
+// interval recurrence then runs on wave-uniform values - read lane by lane with
+// v_readlane - so it executes on the scalar unit; only the 32-bit flushes of
+// the bit accumulator touch memory (lane 0).
+__global__ __launch_bounds__(1024) void range_encode_kernel(
     const float* __restrict__ y, const float* __restrict__ z, const int* __restrict__ meta,
     const uint16_t* __restrict__ tab_y, const uint16_t* __restrict__ tab_z, int Lmax, int M, int HWy,
     int N, int HWz, uint8_t* __restrict__ out, int64_t cap_y, int64_t cap_z,
-    int* __restrict__ lengths, int* __restrict__ err) {
-  __shared__ uint32_t pairs[ENC_CHUNK];
-  const int b = blockIdx.x >> 1, which = blockIdx.x & 1;
+    int* __restrict__ lengths, int* __restrict__ err, int nstreams) {
+  const int lane = threadIdx.x & 63;
+  const int sid = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  if (sid >= nstreams) return;
+  const int b = sid >> 1, which = sid & 1;
   const int C = which ? M : N, HW = which ? HWy : HWz;
   const int64_t n = (int64_t)C * HW;
   const float* sym = which ? y + (size_t)b * n : z + (size_t)b * n;
@@ -148,74 +111,127 @@ __global__ __launch_bounds__(64) void range_encode_kernel(
   const int smin = meta[4 * b + (which ? 0 : 2)], L = meta[4 * b + (which ? 1 : 3)];
   const int64_t stride = cap_z + cap_y;  // per image: [z bytes | y bytes]
   uint8_t* dst = out + (size_t)b * stride + (which ? cap_z : 0);
-  BitSink sink{(uint32_t*)dst, dst, which ? cap_y : cap_z, 0, 0, 0, 0};
-  uint32_t low = 0, high = 0xFFFFFFFFu;
-  uint64_t pending = 0;
-  int bad = (L > Lmax || L < 1);
-
-  for (int64_t base = 0; base < n && !bad; base += ENC_CHUNK) {
-    const int cnt = (int)((n - base) < ENC_CHUNK ? (n - base) : ENC_CHUNK);
-    for (int i = threadIdx.x; i < cnt; i += 64) {
-      const int64_t g = base + i;
-      const int c = (int)(g / HW);
-      const int s = (int)sym[g] - smin;
-      int sc = s;
-      if (s < 0 || s >= L) {  // cannot happen when meta came from dsic_latent_support on the same latents
-        atomicOr(err, 2);
-        sc = 0;
-      }
-      const uint16_t* t = tab + (size_t)c * Lmax;
-      const uint32_t c_low = t[sc];
-      const uint32_t c_high = (sc == L - 1) ? 0x10000u : (uint32_t)t[sc + 1];
-      const uint32_t pr = c_low | ((c_high - 1u) << 16);
-      pairs[i] = pr;
+  uint32_t* dst32 = (uint32_t*)dst;
+  const int64_t cap = which ? cap_y : cap_z;
+  if (L > Lmax || L < 1) {
+    if (lane == 0) {
+      atomicOr(err, 1);
+      lengths[2 * b + which] = 0;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      for (int i = 0; i < cnt; ++i) {
-        const uint32_t pr = pairs[i];
-        const uint64_t c_low = pr & 0xFFFFu, c_high = (uint64_t)(pr >> 16) + 1u;
-        const uint64_t span = (uint64_t)high - (uint64_t)low + 1u;
-        high = (low - 1u) + (uint32_t)((span * c_high) >> 16);
-        low = low + (uint32_t)((span * c_low) >> 16);
-        // E1/E2: n leading bits agree -> emit them (pending inverse bits after the first)
-        const uint32_t x = low ^ high;
-        const int nb = x ? __clz((int)x) : 32;
-        if (nb > 0) {
-          const uint32_t first = low >> 31;
-          sink.put(first, 1);
-          sink.put_run(first ? 0 : 1, pending);
-          pending = 0;
-          if (nb > 1) sink.put((low << 1) >> (33 - nb), nb - 1);
-          if (nb == 32) {
-            low = 0;
-            high = 0xFFFFFFFFu;
-          } else {
-            low <<= nb;
-            high = (high << nb) | ((1u << nb) - 1u);
-          }
-        }
-        // E3: low = 01.., high = 10..: m consecutive (1,0) pairs below the MSB
-        const uint32_t e3 = (low << 1) & ~(high << 1);
-        const int m = __clz((int)~e3);  // leading ones of e3 (<= 31 since bit 0 of e3 is 0)
-        if (m > 0) {
-          pending += (uint64_t)m;
-          low = (low << m) & 0x7FFFFFFFu;
-          high = (high << m) | 0x80000000u | ((1u << m) - 1u);
-        }
-      }
-    }
-    __syncthreads();
+    return;
   }
-  if (threadIdx.x == 0) {
-    pending += 1;
-    const uint32_t bit = low < 0x40000000u ? 0u : 1u;
-    sink.put(bit, 1);
-    sink.put_run(bit ? 0 : 1, pending);
-    sink.finish();
-    lengths[2 * b + which] = (int)sink.nbytes;
-    if (sink.overflow) atomicOr(err, 4);
-    if (bad) atomicOr(err, 1);
+
+  // Two-deep software pipeline for the operand gather: symbols are loaded two
+  // groups ahead, their table entries one group ahead, so neither dependent
+  // load round sits on the serial chain even when L2 latency is several
+  // microseconds under a co-running conv kernel.
+  auto sym_of = [&](int64_t g) -> float { return g < n ? sym[g] : 0.f; };
+  auto pair_of = [&](float v, int64_t g) -> uint32_t {
+    if (g >= n) return 0u;
+    const int c = (int)(g / HW);
+    int sc = (int)v - smin;
+    if (sc < 0 || sc >= L) {  // cannot happen when meta came from dsic_latent_support on the same latents
+      atomicOr(err, 2);
+      sc = 0;
+    }
+    const uint16_t* t = tab + (size_t)c * Lmax;
+    const uint32_t c_low = t[sc];
+    const uint32_t c_high = (sc == L - 1) ? 0x10000u : (uint32_t)t[sc + 1];
+    return c_low | ((c_high - 1u) << 16);
+  };
+
+  uint32_t low = 0, high = 0xFFFFFFFFu, pending = 0;
+  uint64_t acc = 0;   // bit accumulator, newest bit at the bottom
+  int nbits = 0;      // valid bits in acc (< 32 between symbols)
+  int64_t nbytes = 0;
+  int overflow = 0;
+
+  auto put = [&](uint32_t v, int len) {  // append the low `len` (1..32) bits of v
+    acc = (acc << len) | (uint64_t)v;
+    nbits += len;
+    if (nbits >= 32) {
+      const uint32_t w = (uint32_t)(acc >> (nbits - 32));
+      if (nbytes + 4 <= cap) {
+        dst32[nbytes >> 2] = __builtin_bswap32(w);  // every lane stores the same dword: keeps the state scalar
+      } else {
+        overflow = 1;
+      }
+      nbytes += 4;
+      nbits -= 32;
+    }
+  };
+  auto put_run = [&](uint32_t bit, uint32_t count) {
+    while (count > 0) {
+      const int len = count > 32 ? 32 : (int)count;
+      put(bit ? (len == 32 ? 0xFFFFFFFFu : ((1u << len) - 1u)) : 0u, len);
+      count -= len;
+    }
+  };
+
+  uint32_t cur = pair_of(sym_of(lane), lane);
+  float sym1 = sym_of(64 + lane);
+  for (int64_t base = 0; base < n; base += 64) {
+    const float sym2 = sym_of(base + 128 + lane);
+    const uint32_t nxt = pair_of(sym1, base + 64 + lane);
+    const int cnt = (int)((n - base) < 64 ? (n - base) : 64);
+    for (int j = 0; j < cnt; ++j) {
+      const uint32_t pr = __builtin_amdgcn_readlane(cur, j);
+      const uint32_t c_low = pr & 0xFFFFu, c_high = (pr >> 16) + 1u;
+      // span = high - low + 1 (up to 2^32): (span*c) >> 16 == (r*c + c) >> 16 with r = high - low
+      const uint32_t r = high - low;
+      const uint32_t hi_add = (uint32_t)(((uint64_t)r * c_high + c_high) >> 16);
+      const uint32_t lo_add = (uint32_t)(((uint64_t)r * c_low + c_low) >> 16);
+      high = (low - 1u) + hi_add;
+      low = low + lo_add;
+      // Between symbols high - low >= 2^30 (MSBs differ, no E3 pending), every
+      // table interval is >= 1/65536, so the new interval is >= 2^14 - 2 wide:
+      // low != high and at most 18 leading bits agree.
+      // E1/E2: nb leading bits agree -> emit them (pending inverse bits after the first)
+      const int nb = __builtin_clz(low ^ high);
+      if (nb > 0) {
+        if (pending == 0) {
+          put(low >> (32 - nb), nb);
+        } else {
+          const uint32_t first = low >> 31;
+          put(first, 1);
+          put_run(first ^ 1u, pending);
+          pending = 0;
+          if (nb > 1) put((low << 1) >> (33 - nb), nb - 1);
+        }
+        low <<= nb;
+        high = (high << nb) | ((1u << nb) - 1u);
+      }
+      // E3: low = 01.., high = 10..: m consecutive (1,0) pairs below the MSB
+      const uint32_t e3 = (low << 1) & ~(high << 1);  // bit 0 is 0, so ~e3 != 0
+      const int m = __builtin_clz(~e3);
+      if (m > 0) {
+        pending += (uint32_t)m;
+        low = (low << m) & 0x7FFFFFFFu;
+        high = (high << m) | 0x80000000u | ((1u << m) - 1u);
+      }
+    }
+    cur = nxt;
+    sym1 = sym2;
+  }
+  // flush (torchac): one more pending bit, then the deciding bit and the pending run
+  pending += 1;
+  const uint32_t bit = low < 0x40000000u ? 0u : 1u;
+  put(bit, 1);
+  put_run(bit ^ 1u, pending);
+  while (nbits > 0) {  // tail bytes, zero padded
+    const int take = nbits >= 8 ? 8 : nbits;
+    const uint32_t v = (uint32_t)((acc >> (nbits - take)) & ((1u << take) - 1u)) << (8 - take);
+    if (nbytes < cap) {
+      dst[nbytes] = (uint8_t)v;
+    } else {
+      overflow = 1;
+    }
+    nbytes += 1;
+    nbits -= take;
+  }
+  if (lane == 0) {
+    lengths[2 * b + which] = (int)nbytes;
+    if (overflow) atomicOr(err, 4);
   }
 }
 
@@ -344,14 +360,17 @@ extern "C" int dsic_cdf_tables_student(const float* sigma, const float* nu, cons
 extern "C" int dsic_range_encode(const float* y_nchw, const float* z_nchw, const int* meta,
                                  const uint16_t* tab_y, const uint16_t* tab_z, int Lmax, int B, int M,
                                  int HWy, int N, int HWz, uint8_t* out, int64_t cap_y, int64_t cap_z,
-                                 int* lengths, int* err, void* stream) {
+                                 int* lengths, int* err, int streams_per_wg, void* stream) {
   DSIC_REQUIRE(y_nchw && z_nchw && meta && tab_y && tab_z && out && lengths && err,
                "range_encode: null pointer");
   DSIC_REQUIRE(B > 0 && M > 0 && N > 0 && HWy > 0 && HWz > 0, "range_encode: empty latent");
   DSIC_REQUIRE(cap_y % 4 == 0 && cap_z % 4 == 0 && cap_y >= 8 && cap_z >= 8,
                "range_encode: capacities must be multiples of 4 and >= 8");
-  hipLaunchKernelGGL(range_encode_kernel, dim3(2 * B), dim3(64), 0, (hipStream_t)stream, y_nchw, z_nchw,
-                     meta, tab_y, tab_z, Lmax, M, HWy, N, HWz, out, cap_y, cap_z, lengths, err);
+  DSIC_REQUIRE(streams_per_wg >= 1 && streams_per_wg <= 16, "range_encode: streams_per_wg must be in [1,16]");
+  hipLaunchKernelGGL(range_encode_kernel, dim3(ceil_div(2 * B, streams_per_wg)), dim3(64 * streams_per_wg), 0,
+                     (hipStream_t)stream,
+                     y_nchw, z_nchw, meta, tab_y, tab_z, Lmax, M, HWy, N, HWz, out, cap_y, cap_z, lengths,
+                     err, 2 * B);
   return check_launch("range_encode");
 }
 
@@ -365,6 +384,29 @@ extern "C" int dsic_range_decode(const uint8_t* in, int64_t stride, const int* l
   hipLaunchKernelGGL(range_decode_kernel, dim3(B), dim3(64), 48 * 1024, (hipStream_t)stream, in, stride,
                      lengths, lstride, loff, meta, meta_off, tables, Lmax, C, HW, out_nchw, err);
   return check_launch("range_decode");
+}
+
+// A HIP stream restricted to a subset of the compute units (mask bit i = CU i
+// enabled).  Lets the serial range coder own a few CUs while the conv kernels
+// of the next batch run on the others.  The caller destroys it.
+extern "C" int dsic_stream_create_masked(const uint32_t* mask_host, int words, void** stream_out) {
+  DSIC_REQUIRE(mask_host && stream_out && words >= 1, "stream_create_masked: bad argument");
+  hipStream_t st = nullptr;
+  hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask_host);
+  if (e != hipSuccess) {
+    set_error("hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
+    return DSIC_EHIP;
+  }
+  *stream_out = (void*)st;
+  return DSIC_OK;
+}
+extern "C" int dsic_stream_destroy(void* stream) {
+  hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  if (e != hipSuccess) {
+    set_error("hipStreamDestroy: %s", hipGetErrorString(e));
+    return DSIC_EHIP;
+  }
+  return DSIC_OK;
 }
 
 // Host-side evaluation of the same table math (CPU tests compare it with the

@@ -76,7 +76,7 @@ def _cap(n):
 
 
 @torch.no_grad()
-def compress_latents(y_tilde, z_tilde, sigma_y, nu_y, sigma_z, tail=10, Lmax=DEFAULT_LMAX):
+def compress_latents(y_tilde, z_tilde, sigma_y, nu_y, sigma_z, tail=10, Lmax=DEFAULT_LMAX, streams_per_wg=4):
     """Device-resident compress of already computed latents.
 
     y_tilde [B,M,Hy,Wy], z_tilde [B,N,Hz,Wz] integer-valued (quant_mode="round");
@@ -96,9 +96,64 @@ def compress_latents(y_tilde, z_tilde, sigma_y, nu_y, sigma_z, tail=10, Lmax=DEF
     lengths = torch.zeros((B, 2), dtype=torch.int32, device=dev)
     _lib.check(_lib.load().dsic_range_encode(_p(y), _p(z), _p(meta), _p(tab_y), _p(tab_z), Lmax, B, M, Hy * Wy,
                                              N, Hz * Wz, _p(out), cap_y, cap_z, _p(lengths), _p(err),
-                                             _stream()), "range_encode")
+                                             int(streams_per_wg), _stream()), "range_encode")
     return {"bytes": out, "lengths": lengths, "meta": meta, "cap_z": cap_z, "cap_y": cap_y,
             "tab_y": tab_y, "tab_z": tab_z, "err": err, "shape_y": list(y.shape), "shape_z": list(z.shape)}
+
+
+def masked_streams(coder_cus, total_cus=256):
+    """(main, coder) torch ExternalStreams: the coder owns the LAST `coder_cus`
+    CUs of the mask order, everything else runs on the remaining ones."""
+    L = _lib.load()
+    words = (total_cus + 31) // 32
+    bits = np.zeros(total_cus, dtype=bool)
+    bits[total_cus - coder_cus:] = True
+
+    def make(sel):
+        m = np.zeros(words, dtype=np.uint32)
+        for i in np.nonzero(sel)[0]:
+            m[i // 32] |= np.uint32(1 << (i % 32))
+        h = ctypes.c_void_p()
+        _lib.check(L.dsic_stream_create_masked(m.ctypes.data_as(ctypes.c_void_p), words, ctypes.byref(h)),
+                   "stream_create_masked")
+        return torch.cuda.ExternalStream(h.value)
+
+    return make(~bits), make(bits)
+
+
+class AsyncCompressor:
+    """Runs compress_latents on a side HIP stream so that the serial range coder
+    overlaps synthesis (and the next batch's analysis).  Use as the `after_rate`
+    hook of CompressionModel.forward; call .wait() before reading `.last`."""
+
+    def __init__(self, model, tail=10, Lmax=DEFAULT_LMAX, stream=None, streams_per_wg=4):
+        self.model, self.tail, self.Lmax = model, tail, Lmax
+        self.streams_per_wg = streams_per_wg
+        self.stream = stream if stream is not None else torch.cuda.Stream()
+        self.last = None
+        self._sigma_z = None
+
+    def __call__(self, partial):
+        main = torch.cuda.current_stream()
+        if self._sigma_z is None:
+            self._sigma_z = torch.exp(self.model.z_prior.log_sigma).contiguous()
+            self._sigma_z.record_stream(self.stream)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        tensors = [partial["y_tilde"], partial["z_tilde"], partial["sigma"], partial["nu"]]
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            for t in tensors:
+                t.record_stream(self.stream)      # allocator must not recycle them under the coder
+            self.last = compress_latents(tensors[0], tensors[1], tensors[2], tensors[3], self._sigma_z,
+                                         self.tail, self.Lmax, self.streams_per_wg)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+            self.last["done"] = done
+
+    def wait(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+        return self.last
 
 
 def _per_channel(t):

@@ -50,7 +50,9 @@ SIGNATURES = {
     "dsic_cdf_tables_gauss": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P]),
     "dsic_cdf_tables_student": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P]),
     "dsic_range_encode": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P,
-                                  c_int64, c_int64, _P, _P, _P]),
+                                  c_int64, c_int64, _P, _P, c_int, _P]),
+    "dsic_stream_create_masked": (c_int, [_P, c_int, _P]),
+    "dsic_stream_destroy": (c_int, [_P]),
     "dsic_range_decode": (c_int, [_P, c_int64, _P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int,
                                   c_int, _P, _P, _P]),
     "dsic_host_normal_cdf": (ctypes.c_double, [ctypes.c_double]),

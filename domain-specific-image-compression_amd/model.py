@@ -49,8 +49,12 @@ class CompressionModel(nn.Module):
             raise ValueError(f"Unknown quant mode: {mode}")
 
     @torch.no_grad()
-    def forward(self, x, quant_mode="noise", collect_taps=False):
-        """model.py:37-72.  x: [B,C,H,W] float32 on the GPU, H and W multiples of 16."""
+    def forward(self, x, quant_mode="noise", collect_taps=False, after_rate=None):
+        """model.py:37-72.  x: [B,C,H,W] float32 on the GPU, H and W multiples of 16.
+
+        `after_rate(partial)` (optional) is called once the latents, sigma/nu and
+        the rate terms are enqueued and BEFORE synthesis is launched, so a caller
+        can start the range coder on a second HIP stream beside g_s."""
         if quant_mode not in ("noise", "round"):
             raise ValueError(f"Unknown quant mode: {quant_mode}")
         if x.dim() != 4:
@@ -69,6 +73,9 @@ class CompressionModel(nn.Module):
             z_in = ops.round_half_even(z)
         (log_sigma, log_nu, sigma, nu), _ = self.h_s.params_nhwc(z_in, self.min_nu, self.max_nu, taps)
         r = ops.rate(y, z, sigma, nu, self.z_prior.log_sigma, y_noisy, z_noisy)
+        if after_rate is not None:
+            after_rate({"y_tilde": r["y_tilde"], "z_tilde": r["z_tilde"], "sigma": sigma, "nu": nu,
+                        "sums": r["sums"]})
         # model.py:62: eval mode synthesises from round(y), training from y_tilde
         y_hat = r["y_hat_nhwc"] if not self.training else (y_noisy if y_noisy is not None else r["y_hat_nhwc"])
         x_hat = self.g_s.forward_nhwc(y_hat, taps)

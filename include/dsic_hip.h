@@ -200,7 +200,7 @@ int dsic_range_encode(const float* y_nchw, const float* z_nchw, const int* meta,
                       const uint16_t* tab_y, const uint16_t* tab_z, int Lmax,
                       int B, int M, int HWy, int N, int HWz, uint8_t* out,
                       int64_t cap_y, int64_t cap_z, int* lengths, int* err,
-                      void* stream);
+                      int streams_per_wg, void* stream);
 
 /* torchac.decode_float_cdf call sites :96,116: string b starts at
  * in + b*stride and has lengths[b*lstride + loff] bytes; meta_off 0 = y, 2 = z.
@@ -209,6 +209,14 @@ int dsic_range_decode(const uint8_t* in, int64_t stride, const int* lengths,
                       int lstride, int loff, const int* meta, int meta_off,
                       const uint16_t* tables, int Lmax, int B, int C, int HW,
                       float* out_nchw, int* err, void* stream);
+
+/* HIP stream limited to the CUs whose bit is set in mask_host[words] (bit i of
+ * word i/32 = CU i).  Used to give the range coder its own few CUs beside the
+ * conv kernels; there is no reference counterpart (the reference is
+ * single-stream).  The caller destroys the stream. */
+int dsic_stream_create_masked(const uint32_t* mask_host, int words,
+                              void** stream_out);
+int dsic_stream_destroy(void* stream);
 
 /* The table math evaluated on the HOST (no GPU needed): lets CPU-only tests
  * compare it bit for bit with the oracle.  out_host: L uint16 in host memory. */
