@@ -103,10 +103,8 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+    from dsic_amd import distributed as D
+    D.init("nccl", dev)                                  # RCCL over xGMI when world > 1
 
     from dsic_amd import entropy, metrics, ops, synthetic as S
     from dsic_amd.model import CompressionModel
@@ -117,7 +115,7 @@ def main():
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     model = model.to(dev).eval()
     # this rank's slice of the global batch, resident in HBM before timing
-    patches = S.make_patches(rank * B, B, H, W, C)
+    patches = S.make_patches(D.shard_first_index(rank, B), B, H, W, C)
     x = torch.from_numpy(patches).to(dev)
 
     timer = KernelTimer()
@@ -154,8 +152,7 @@ def main():
                 torch.cuda.current_stream().wait_event(prev["done"])
                 real = prev["lengths"].sum().double() * 8.0 / float(H * W)   # eval_selfcontained_entropy.py:148-149
         t = torch.stack([bpp.sum(), msssim.double().sum(), count, real])
-        if world > 1:
-            dist.all_reduce(t)                                   # the one collective: 4 x fp64
+        D.reduce_metric_sums(t)                                  # the one collective: 4 x fp64
         totals.copy_(t)
         return out
 
@@ -163,8 +160,7 @@ def main():
         step()
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        D.barrier()
         torch.cuda.synchronize()
 
     barrier()
@@ -173,15 +169,15 @@ def main():
     for _ in range(args.steps):
         step()
     if coder is not None:
-        last = coder.wait()
-        totals[3] = last["lengths"].sum().double() * 8.0 / float(H * W) * (world if world > 1 else 1)
+        last = coder.wait()                                      # strings of the final step
+        extra = torch.zeros(4, dtype=torch.float64, device=dev)
+        extra[3] = last["lengths"].sum().double() * 8.0 / float(H * W)
+        D.reduce_metric_sums(extra)
+        totals[3] = extra[3]
     barrier()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = D.max_over_ranks(elapsed, dev)
 
     tot = totals.cpu().numpy()
     n_img = tot[2]
@@ -251,7 +247,7 @@ def main():
             }
         print(json.dumps(res))
     if world > 1:
-        dist.destroy_process_group()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
