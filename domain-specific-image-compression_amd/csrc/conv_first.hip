@@ -1,0 +1,157 @@
+// First analysis layer: conv(Cimg, 128, 3, 1) + GDN (code/modelv2/layers.py:51)
+// straight from the NCHW image, as an fp32 MFMA GEMM with K = 9*Cimg (27 -> 28,
+// or 36 for 4 bands) instead of the generic kernel's 8-channel-padded K = 72.
+//
+// The layer is bound by its 512-byte-per-pixel NHWC output (33.5 MB per 256^2
+// image), not by MACs: 14 MFMA k-steps per 32x32 tile, weights (28 x 128) held
+// in registers for the whole kernel, the 3 x 10 x 18 input window of a 16x8
+// pixel tile in LDS, A operands gathered with one ds_read_b32 per k-step
+// (k = c*9 + ky*3 + kx, the reference weight order), GDN epilogue + LDS
+// transpose + 16-byte stores as in conv_igemm.hip.
+#include "common.h"
+
+namespace dsic {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+template <int C>
+__global__ __launch_bounds__(256, 2) void conv_first_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ beta, const float* __restrict__ gamma, float* __restrict__ out, int B,
+    int H, int W, int Cout, int act, int tiles_x, int tiles_y) {
+  constexpr int K = 9 * C;
+  constexpr int KP = (K + 1) / 2 * 2;  // even
+  constexpr int NS = KP / 2;           // MFMA k-steps
+  constexpr int TW = 16, TH = 8, WW = TW + 2, WH = TH + 2, RS = 20;  // LDS row stride
+  constexpr int EPI_STRIDE = 36;
+  constexpr int WIN_FLOATS = C * WH * RS;
+  constexpr int EPI_FLOATS = 4 * 32 * EPI_STRIDE;
+  __shared__ __attribute__((aligned(16))) float lds[WIN_FLOATS > EPI_FLOATS ? WIN_FLOATS : EPI_FLOATS];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  int bx = blockIdx.x;
+  const int tile_x = bx % tiles_x;
+  bx /= tiles_x;
+  const int tile_y = bx % tiles_y;
+  const int n = bx / tiles_y;
+  const int ox0 = tile_x * TW, oy0 = tile_y * TH;
+
+  // weights of this wave's 32 output columns: b[s] = Wk[2s+h][col]
+  const int col = wave * 32 + l31;
+  const bool colok = col < Cout;
+  float b[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int k = 2 * s + h;
+    b[s] = (colok && k < K) ? w[(size_t)col * K + k] : 0.f;  // reference layout [Cout][C][3][3]
+  }
+  // per-lane LDS offsets of the A gather
+  int aoff[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    int k = 2 * s + h;
+    if (k >= K) k = 0;  // padded k-step: weight is zero, any valid address
+    const int c = k / 9, t = k % 9;
+    aoff[s] = (c * WH + t / 3) * RS + t % 3;
+  }
+  int abase[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int r = m * 32 + l31;
+    abase[m] = (r / TW) * RS + r % TW;
+  }
+
+  // stage the window (zero padded)
+  const float* xin = x + (size_t)n * C * H * W;
+  for (int i = tid; i < C * WH * WW; i += 256) {
+    const int c = i / (WH * WW), r = (i / WW) % WH, xx = i % WW;
+    const int gy = oy0 - 1 + r, gx = ox0 - 1 + xx;
+    float v = 0.f;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = xin[((size_t)c * H + gy) * W + gx];
+    lds[(c * WH + r) * RS + xx] = v;
+  }
+  __syncthreads();
+
+  floatx16 acc[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    float a[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) a[m] = lds[abase[m] + aoff[s]];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[s], acc[m], 0, 0, 0);
+  }
+  __syncthreads();  // window no longer needed: LDS becomes the transpose scratch
+
+  const float bs = colok ? bias[col] : 0.f;
+  float be = 1.f, ga = 0.f;
+  if (colok && act == DSIC_ACT_GDN) {
+    be = beta[col];
+    ga = gamma[col];
+  }
+  float* epi = lds + wave * (32 * EPI_STRIDE);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
+      float v = __fadd_rn(acc[m][e], bs);
+      if (act == DSIC_ACT_GDN) {
+        const float d = __fsqrt_rn(__fadd_rn(be, __fmul_rn(ga, __fmul_rn(v, v))));
+        v = __fdiv_rn(v, d);
+      } else if (act == DSIC_ACT_RELU) {
+        v = v > 0.f ? v : 0.f;
+      }
+      epi[rr * EPI_STRIDE + l31] = v;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const int c4 = (lane & 7) * 4;
+    const int nn = wave * 32 + c4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = (lane >> 3) + 8 * i;
+      const floatx4 v = *(const floatx4*)(epi + rr * EPI_STRIDE + c4);
+      const int r = m * 32 + rr;
+      const int ox = ox0 + r % TW, oy = oy0 + r / TW;
+      if (oy < H && ox < W && nn < Cout)
+        *(floatx4*)(out + (((size_t)n * H + oy) * W + ox) * Cout + nn) = v;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+}  // namespace dsic
+
+using namespace dsic;
+
+// conv(Cimg,Cout,3,1) (+GDN/ReLU) from the NCHW image to NHWC features
+// (layers.py:51).  w is the REFERENCE weight tensor [Cout][Cimg][3][3], unpacked.
+extern "C" int dsic_conv_first_nchw(const float* x_nchw, const float* w_oihw, const float* bias,
+                                    const float* beta, const float* gamma, float* out_nhwc, int B,
+                                    int Cimg, int H, int W, int Cout, int act, void* stream) {
+  DSIC_REQUIRE(x_nchw && w_oihw && bias && out_nhwc, "conv_first: null pointer");
+  DSIC_REQUIRE(B > 0 && H > 0 && W > 0, "conv_first: empty tensor");
+  DSIC_REQUIRE(Cimg == 3 || Cimg == 4, "conv_first: Cimg=%d must be 3 or 4", Cimg);
+  DSIC_REQUIRE(Cout > 0 && Cout <= 128 && Cout % 4 == 0, "conv_first: Cout=%d must be a multiple of 4, <= 128", Cout);
+  DSIC_REQUIRE(act == DSIC_ACT_NONE || act == DSIC_ACT_GDN || act == DSIC_ACT_RELU, "conv_first: act=%d", act);
+  DSIC_REQUIRE(act != DSIC_ACT_GDN || (beta && gamma), "conv_first: GDN needs beta and gamma");
+  const int tx = ceil_div(W, 16), ty = ceil_div(H, 8);
+  DSIC_REQUIRE((int64_t)tx * ty * B < ((int64_t)1 << 31), "conv_first: grid too large");
+  dim3 grid(tx * ty * B), block(256);
+  if (Cimg == 3)
+    hipLaunchKernelGGL(conv_first_kernel<3>, grid, block, 0, (hipStream_t)stream, x_nchw, w_oihw, bias, beta,
+                       gamma, out_nhwc, B, H, W, Cout, act, tx, ty);
+  else
+    hipLaunchKernelGGL(conv_first_kernel<4>, grid, block, 0, (hipStream_t)stream, x_nchw, w_oihw, bias, beta,
+                       gamma, out_nhwc, B, H, W, Cout, act, tx, ty);
+  return check_launch("conv_first");
+}

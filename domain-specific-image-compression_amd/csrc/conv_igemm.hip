@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256, NTW == 2 ? 1 : 2) void conv_igemm_kernel(const
   int boff[NTW];
 #pragma unroll
   for (int j = 0; j < NTW; ++j) {
-    ntile[j] = NARROW ? 0 : wave + 4 * j;
+    ntile[j] = NARROW ? 0 : (int)blockIdx.z * 4 * NTW + wave + 4 * j;  // blockIdx.z: column block
     nvalid[j] = ntile[j] * 32 < a.CoutP;
     boff[j] = ((nvalid[j] ? ntile[j] : 0) * 32 + l31) * 8 + 4 * h;
   }
@@ -345,24 +345,24 @@ __global__ __launch_bounds__(256, NTW == 2 ? 1 : 2) void conv_igemm_kernel(const
 }
 
 template <int WIN, int S, int CK, int NTW, bool NARROW>
-static int launch_conv(ConvArgs& a, int nphase, hipStream_t st) {
+static int launch_conv(ConvArgs& a, int nphase, int colblocks, hipStream_t st) {
   // tile shape by output-grid width: 16x8x1, 8x8x2, 4x4x8 (cols x rows x images)
   constexpr int CKS = (WIN == 5) ? 8 : CK;  // keep the 4x4x8 window under 64 KB of LDS
   dim3 block(256);
   if (a.Wo > 8) {
     a.tiles_x = ceil_div(a.Wo, 16);
     a.tiles_y = ceil_div(a.Ho, 8);
-    dim3 grid(a.tiles_x * a.tiles_y * a.B, nphase);
+    dim3 grid(a.tiles_x * a.tiles_y * a.B, nphase, colblocks);
     hipLaunchKernelGGL((conv_igemm_kernel<WIN, S, 16, 8, 1, CK, NTW, NARROW>), grid, block, 0, st, a);
   } else if (a.Wo > 4) {
     a.tiles_x = ceil_div(a.Wo, 8);
     a.tiles_y = ceil_div(a.Ho, 8);
-    dim3 grid(a.tiles_x * a.tiles_y * ceil_div(a.B, 2), nphase);
+    dim3 grid(a.tiles_x * a.tiles_y * ceil_div(a.B, 2), nphase, colblocks);
     hipLaunchKernelGGL((conv_igemm_kernel<WIN, S, 8, 8, 2, CK, NTW, NARROW>), grid, block, 0, st, a);
   } else {
     a.tiles_x = ceil_div(a.Wo, 4);
     a.tiles_y = ceil_div(a.Ho, 4);
-    dim3 grid(a.tiles_x * a.tiles_y * ceil_div(a.B, 8), nphase);
+    dim3 grid(a.tiles_x * a.tiles_y * ceil_div(a.B, 8), nphase, colblocks);
     hipLaunchKernelGGL((conv_igemm_kernel<WIN, S, 4, 4, 8, CKS, NTW, NARROW>), grid, block, 0, st, a);
   }
   return check_launch("conv_igemm");
@@ -371,9 +371,16 @@ static int launch_conv(ConvArgs& a, int nphase, hipStream_t st) {
 template <int WIN, int S, int CK>
 static int run_conv_ck(ConvArgs& a, int nphase, hipStream_t st) {
   const int ntiles = a.CoutP / 32;
-  if (ntiles == 1) return launch_conv<WIN, S, CK, 1, true>(a, nphase, st);
-  if (ntiles <= 4) return launch_conv<WIN, S, CK, 1, false>(a, nphase, st);
-  if (ntiles <= 8) return launch_conv<WIN, S, CK, 2, false>(a, nphase, st);
+  if (ntiles == 1) return launch_conv<WIN, S, CK, 1, true>(a, nphase, 1, st);
+  if (ntiles <= 4) return launch_conv<WIN, S, CK, 1, false>(a, nphase, 1, st);
+  if (ntiles <= 8) {
+    // Two column tiles per wave halve the A traffic, but a small grid (the 16x16 latent
+    // layer: 128 workgroups at B=64) leaves CUs idle: then split the columns over blockIdx.z.
+    const int tw = a.Wo > 8 ? 16 : (a.Wo > 4 ? 8 : 4), th = a.Wo > 4 ? 8 : 4, tn = 128 / (tw * th);
+    const long wgs = (long)ceil_div(a.Wo, tw) * ceil_div(a.Ho, th) * ceil_div(a.B, tn) * nphase;
+    if (wgs < 512) return launch_conv<WIN, S, CK, 1, false>(a, nphase, ceil_div(ntiles, 4), st);
+    return launch_conv<WIN, S, CK, 2, false>(a, nphase, 1, st);
+  }
   set_error("conv: Cout=%d too wide (max 256)", a.Cout);
   return DSIC_EINVAL;
 }

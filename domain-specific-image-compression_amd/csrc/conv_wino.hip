@@ -1,0 +1,347 @@
+// Winograd F(2x2,3x3) fp32 convolution for the 3x3 stride-1 layers
+// (conv(N,N,3,1) at code/modelv2/layers.py:56,62,67,86,90,94,108,109) with the
+// same fused bias + GDN/IGDN/ReLU epilogue as conv_igemm.hip.
+//
+// Y = A^T [ sum_c (G g G^T) o (B^T d B) ] A needs 16 multiplies per 2x2 output
+// tile and channel pair instead of 36: 2.25x fewer MFMA flops for the layers
+// that hold 35 % of the model's MACs, at fp32 accuracy (the transforms only add,
+// subtract and halve).  It is the same exact-fp32 MFMA instruction; only the
+// summation order differs from a direct convolution.
+//
+// Workgroup = 512 threads = 8 waves, persistent over output tiles of 16x8 pixels
+// (= 8x4 Winograd tiles = the 32 rows of one MFMA M tile).  The 16 Winograd
+// positions are 16 independent GEMMs  D_p[32 tiles][Cout] += V_p[32][Cin] U_p[Cin][Cout].
+// Wave w owns column tile nt = w&3 (32 output channels) and positions
+// 8*(w>>2) .. +7: 8 accumulators of 32x32 = 128 VGPRs, two waves per SIMD.
+// Per 32-channel chunk every thread loads 12 float4 of the NHWC input
+// (prefetched one chunk ahead, across tiles), transforms its (tile, 4 channels,
+// half of the positions) with 16 float4 add/subs and writes V into a
+// double-buffered LDS image [pos][tile][36]; U (transformed weights, packed
+// [pos][Cin/8][CoutP][8]) streams from L2 into registers.  Epilogue: the two
+// position halves exchange partial inverse transforms through LDS, each wave
+// finishes one output row parity, applies bias + activation and stores 16 bytes
+// per lane through the LDS transpose.
+#include "common.h"
+
+namespace dsic {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+struct WinoArgs {
+  const float* in;
+  const float* u;  // [16][Cin/8][CoutP][8]
+  const float* bias;
+  const float* beta;
+  const float* gamma;
+  float* out;
+  int B, H, W, Cin, Cout, CoutP;
+  int act;
+  int tiles_x, tiles_y, ntiles;  // 16x8-pixel output tiles
+};
+
+__device__ __forceinline__ float wino_act(float v, int act, float beta, float gamma) {
+  if (act == DSIC_ACT_GDN) {
+    const float d = __fsqrt_rn(__fadd_rn(beta, __fmul_rn(gamma, __fmul_rn(v, v))));
+    return __fdiv_rn(v, d);
+  } else if (act == DSIC_ACT_IGDN) {
+    const float d = __fsqrt_rn(__fadd_rn(beta, __fmul_rn(gamma, __fmul_rn(v, v))));
+    return __fmul_rn(v, d);
+  } else if (act == DSIC_ACT_RELU) {
+    return v > 0.f ? v : 0.f;
+  }
+  return v;
+}
+
+constexpr int WCK = 32;                    // channels per chunk
+constexpr int WP = WCK + 4;                // LDS floats per (pos, tile) row
+constexpr int WBUF = 16 * 32 * WP;         // floats per V buffer
+constexpr int WLDS_BYTES = 2 * WBUF * 4;   // 147456
+
+__global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const int nt = wave & 3, ph = wave >> 2;
+  const int Cin = a.Cin, Cin8 = Cin >> 3;
+  const int nchunks = Cin / WCK;
+  const bool nvalid = nt * 32 < a.CoutP;
+  const int wstep = a.CoutP * 8;
+  const int boff = ((nvalid ? nt : 0) * 32 + l31) * 8 + 4 * h;
+
+  // producer role of this thread: Winograd tile pt, channel quad pq, position half pr
+  const int pt = tid >> 4, pq = (tid >> 1) & 7, pr = tid & 1;
+  const int ptx = pt & 7, pty = pt >> 3;
+  // pr = 0 computes xi in {0,1} from input rows 0,1,2; pr = 1 computes xi in {2,3} from rows 1,2,3
+  const int vwrite = ((pr * 8) * 32 + pt) * WP + 4 * pq;  // + (xi_local*4 + nu)*32*WP
+
+  floatx4 raw[12];
+  int cur_tile = blockIdx.x;
+  // ---- producer: issue the loads of (tile, chunk) -----------------------------------------
+  auto issue = [&](int tile, int chunk) {
+    const int tx = tile % a.tiles_x;
+    const int ty = (tile / a.tiles_x) % a.tiles_y;
+    const int n = tile / (a.tiles_x * a.tiles_y);
+    const int gy0 = ty * 8 + 2 * pty - 1 + pr, gx0 = tx * 16 + 2 * ptx - 1;
+    const float* base = a.in + (size_t)n * a.H * a.W * Cin + chunk * WCK + 4 * pq;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int gy = gy0 + i, gx = gx0 + j;
+        floatx4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+          v = *(const floatx4*)(base + ((size_t)gy * a.W + gx) * Cin);
+        raw[i * 4 + j] = v;
+      }
+  };
+  // ---- producer: B^T d B for this thread's two xi rows, write to V buffer -----------------
+  auto transform = [&](float* vbuf) {
+    floatx4 t[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (pr == 0) {
+        t[0][j] = raw[0 * 4 + j] - raw[2 * 4 + j];  // xi0 = d0 - d2
+        t[1][j] = raw[1 * 4 + j] + raw[2 * 4 + j];  // xi1 = d1 + d2
+      } else {                                      // local rows are d1,d2,d3
+        t[0][j] = raw[1 * 4 + j] - raw[0 * 4 + j];  // xi2 = d2 - d1
+        t[1][j] = raw[0 * 4 + j] - raw[2 * 4 + j];  // xi3 = d1 - d3
+      }
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const floatx4 v0 = t[x][0] - t[x][2];
+      const floatx4 v1 = t[x][1] + t[x][2];
+      const floatx4 v2 = t[x][2] - t[x][1];
+      const floatx4 v3 = t[x][1] - t[x][3];
+      float* dst = vbuf + vwrite + (x * 4) * 32 * WP;
+      *(floatx4*)(dst + 0 * 32 * WP) = v0;
+      *(floatx4*)(dst + 1 * 32 * WP) = v1;
+      *(floatx4*)(dst + 2 * 32 * WP) = v2;
+      *(floatx4*)(dst + 3 * 32 * WP) = v3;
+    }
+  };
+
+  floatx16 acc[8];
+  const int aread = ((ph * 8) * 32 + l31) * WP + 4 * h;  // + p*32*WP + sub*8
+
+  if (cur_tile < a.ntiles) {
+    issue(cur_tile, 0);
+    transform(lds);
+    __syncthreads();
+  }
+  int buf = 0;
+  while (cur_tile < a.ntiles) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
+    const int next_tile = cur_tile + gridDim.x;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      // prefetch the raw input of the next (tile, chunk)
+      const bool last = chunk + 1 == nchunks;
+      const bool have_next = !last || next_tile < a.ntiles;
+      if (have_next) issue(last ? next_tile : cur_tile, last ? 0 : chunk + 1);
+      // consumer: 8 positions x 4 sub-chunks x 4 k-steps
+      const float* vb = lds + buf * WBUF + aread;
+      const float* ub = a.u + (size_t)(chunk * 4) * wstep + boff;
+      floatx4 A0, B0, A1, B1;
+      A0 = *(const floatx4*)(vb);
+      B0 = *(const floatx4*)(ub + (size_t)((ph * 8) * Cin8) * wstep);
+#pragma unroll
+      for (int it = 0; it < 32; it += 2) {  // it = sub*8 + p
+        {
+          const int p1 = (it + 1) & 7, s1 = (it + 1) >> 3;
+          A1 = *(const floatx4*)(vb + p1 * 32 * WP + s1 * 8);
+          B1 = *(const floatx4*)(ub + (size_t)((ph * 8 + p1) * Cin8 + s1) * wstep);
+        }
+        {
+          const int p0 = it & 7;
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[s], B0[s], acc[p0], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
+        }
+        if (it + 2 < 32) {
+          const int p2 = (it + 2) & 7, s2 = (it + 2) >> 3;
+          A0 = *(const floatx4*)(vb + p2 * 32 * WP + s2 * 8);
+          B0 = *(const floatx4*)(ub + (size_t)((ph * 8 + p2) * Cin8 + s2) * wstep);
+        }
+        {
+          const int p1 = (it + 1) & 7;
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            acc[p1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[s], B1[s], acc[p1], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
+        }
+      }
+      // producer: transform the prefetched chunk into the other buffer
+      if (have_next) transform(lds + (buf ^ 1) * WBUF);
+      __syncthreads();
+      buf ^= 1;
+    }
+
+    // ---- inverse transform + epilogue ------------------------------------------------------
+    // Wave (nt, ph) holds M[xi][nu] for xi in {2ph, 2ph+1}.  N[xi][j] = (M A)[xi][j]:
+    //   N[.][0] = M0 + M1 + M2,  N[.][1] = M1 - M2 - M3.
+    // Y[i][j] = (A^T N)[i][j]:  Y[0] = N0 + N1 + N2,  Y[1] = N1 - N2 - N3.
+    // ph=0 finishes row i=0 and needs N2 from ph=1; ph=1 finishes i=1 and needs N1 from ph=0.
+    floatx16 n0[2], n1[2];  // [j] for local xi 0 and 1
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (j == 0) {
+        n0[0] = acc[0] + acc[1] + acc[2];
+        n1[0] = acc[4] + acc[5] + acc[6];
+      } else {
+        n0[1] = acc[1] - acc[2] - acc[3];
+        n1[1] = acc[5] - acc[6] - acc[7];
+      }
+    }
+    // exchange area (inside the V buffer that the next tile's first chunk does NOT use)
+    float* xch = lds + (buf ^ 1) * WBUF;  // 4 nt x 2 ph x 2 j x 16 e x 64 lanes = 16384 floats
+    // what the partner needs: ph=0 sends N1 (its local xi=1), ph=1 sends N2 (its local xi=0)
+    {
+      float* dst = xch + ((nt * 2 + ph) * 2) * 1024 + lane;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dst[j * 1024 + e * 64] = ph == 0 ? n1[j][e] : n0[j][e];
+    }
+    __syncthreads();
+    floatx16 yv[2];
+    {
+      const float* src = xch + ((nt * 2 + (ph ^ 1)) * 2) * 1024 + lane;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float o = src[j * 1024 + e * 64];
+          // ph=0: Y[0] = N0 + N1 + N2(other);  ph=1: Y[1] = N1(other) - N2 - N3
+          yv[j][e] = ph == 0 ? (n0[j][e] + n1[j][e]) + o : (o - n0[j][e]) - n1[j][e];
+        }
+    }
+    __syncthreads();  // exchange area free again (it is the next chunk's transform target)
+
+    if (nvalid) {
+      const int tx = cur_tile % a.tiles_x;
+      const int ty = (cur_tile / a.tiles_x) % a.tiles_y;
+      const int n = cur_tile / (a.tiles_x * a.tiles_y);
+      const int col = nt * 32 + l31;
+      const bool cok = col < a.Cout;
+      const float bias = cok ? a.bias[col] : 0.f;
+      float beta = 1.f, gamma = 0.f;
+      if (cok && (a.act == DSIC_ACT_GDN || a.act == DSIC_ACT_IGDN)) {
+        beta = a.beta[col];
+        gamma = a.gamma[col];
+      }
+      // per-wave transpose patch: overlays the exchange area, which is free after the barrier above
+      float* epi = xch + wave * (32 * 36);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
+          epi[rr * 36 + l31] = wino_act(__fadd_rn(yv[j][e], bias), a.act, beta, gamma);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const int c4 = (lane & 7) * 4;
+        const int nn = nt * 32 + c4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int rr = (lane >> 3) + 8 * i;  // Winograd tile index 0..31
+          const floatx4 v = *(const floatx4*)(epi + rr * 36 + c4);
+          const int oy = ty * 8 + 2 * (rr >> 3) + ph;
+          const int ox = tx * 16 + 2 * (rr & 7) + j;
+          if (oy < a.H && ox < a.W && nn < a.Cout)
+            *(floatx4*)(a.out + (((size_t)n * a.H + oy) * a.W + ox) * a.Cout + nn) = v;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __syncthreads();  // transpose patches done before the next tile's producers reuse the area
+    cur_tile = next_tile;
+  }
+}
+
+// U_p = G g G^T per (cout, cin), packed [16][Cin/8][CoutP][8].
+__global__ void pack_wino_weight_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout,
+                                        int Cin, int Cin8, int CoutP, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int j = i & 7;
+  int64_t r = i >> 3;
+  const int n = r % CoutP;
+  r /= CoutP;
+  const int c8 = r % Cin8;
+  const int p = r / Cin8;
+  const int xi = p >> 2, nu = p & 3;
+  const int c = c8 * 8 + j;
+  float v = 0.f;
+  if (n < Cout && c < Cin) {
+    const float* g = w + ((size_t)n * Cin + c) * 9;
+    // row combination (G g)[xi][kx], then column combination with G^T
+    float row[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const float g0 = g[0 * 3 + kx], g1 = g[1 * 3 + kx], g2 = g[2 * 3 + kx];
+      row[kx] = xi == 0 ? g0 : (xi == 1 ? 0.5f * ((g0 + g1) + g2) : (xi == 2 ? 0.5f * ((g0 - g1) + g2) : g2));
+    }
+    v = nu == 0 ? row[0]
+                : (nu == 1 ? 0.5f * ((row[0] + row[1]) + row[2])
+                           : (nu == 2 ? 0.5f * ((row[0] - row[1]) + row[2]) : row[2]));
+  }
+  dst[i] = v;
+}
+
+}  // namespace dsic
+
+using namespace dsic;
+
+extern "C" int64_t dsic_wino_weight_floats(int Cout, int Cin) {
+  return (int64_t)16 * (round_up(Cin, 8) / 8) * round_up(Cout, 32) * 8;
+}
+
+extern "C" int dsic_pack_wino_weight(const float* w_oihw, float* dst, int Cout, int Cin, void* stream) {
+  DSIC_REQUIRE(w_oihw && dst && Cout > 0 && Cin > 0, "pack_wino_weight: bad argument");
+  const int Cin8 = round_up(Cin, 8) / 8, CoutP = round_up(Cout, 32);
+  const int64_t total = dsic_wino_weight_floats(Cout, Cin);
+  hipLaunchKernelGGL(pack_wino_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, w_oihw, dst, Cout, Cin, Cin8, CoutP, total);
+  return check_launch("pack_wino_weight");
+}
+
+extern "C" int dsic_conv3x3_wino_nhwc(const float* in, const float* u_packed, const float* bias,
+                                      const float* beta, const float* gamma, float* out, int B, int H,
+                                      int W, int Cin, int Cout, int act, void* stream) {
+  DSIC_REQUIRE(in && u_packed && bias && out, "conv3x3_wino: null pointer");
+  DSIC_REQUIRE(B > 0 && H > 0 && W > 0, "conv3x3_wino: empty tensor");
+  DSIC_REQUIRE(Cin > 0 && Cin % 32 == 0, "conv3x3_wino: Cin=%d must be a positive multiple of 32", Cin);
+  DSIC_REQUIRE(Cout > 0 && Cout % 4 == 0 && Cout <= 128, "conv3x3_wino: Cout=%d must be a multiple of 4, <= 128", Cout);
+  DSIC_REQUIRE(act >= 0 && act <= 3, "conv3x3_wino: act=%d", act);
+  DSIC_REQUIRE(!(act == DSIC_ACT_GDN || act == DSIC_ACT_IGDN) || (beta && gamma), "conv3x3_wino: GDN needs beta and gamma");
+  WinoArgs a{};
+  a.in = in; a.u = u_packed; a.bias = bias; a.beta = beta; a.gamma = gamma; a.out = out;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.CoutP = round_up(Cout, 32); a.act = act;
+  a.tiles_x = ceil_div(W, 16); a.tiles_y = ceil_div(H, 8);
+  const int64_t nt = (int64_t)a.tiles_x * a.tiles_y * B;
+  DSIC_REQUIRE(nt < ((int64_t)1 << 31), "conv3x3_wino: too many tiles");
+  a.ntiles = (int)nt;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       WLDS_BYTES);
+    if (e != hipSuccess) {
+      set_error("conv3x3_wino: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return DSIC_EHIP;
+    }
+    attr_set = true;
+  }
+  const int grid = a.ntiles < 256 ? a.ntiles : 256;  // persistent: one workgroup per CU
+  hipLaunchKernelGGL(conv_wino_kernel, dim3(grid), dim3(512), WLDS_BYTES, (hipStream_t)stream, a);
+  return check_launch("conv3x3_wino");
+}

@@ -14,7 +14,12 @@ import math
 import torch
 import torch.nn as nn
 
+import os
+
 from . import ops
+
+# DSIC_WINOGRAD=0 forces the direct implicit-GEMM kernel for every layer (A/B runs)
+USE_WINOGRAD = os.environ.get("DSIC_WINOGRAD", "1") != "0"
 
 
 class _GammaConv(nn.Module):
@@ -97,10 +102,25 @@ class Conv2d(_ConvBase):
             return self.weight.view(self.out_channels, self.in_channels).t().contiguous()
         return ops.pack_conv_weight(self.weight)
 
+    @property
+    def use_winograd(self):
+        """3x3 stride-1 layers with MFMA-friendly channel counts run as Winograd F(2x2,3x3)."""
+        return (USE_WINOGRAD and self.kernel_size == 3 and self.stride == 1 and self.in_channels % 32 == 0
+                and self.out_channels % 4 == 0 and 64 <= self.out_channels <= 128)
+
+    def packed_wino(self):
+        key = self._key()
+        if getattr(self, "_wino", None) is None or self._wino_key != key:
+            self._wino = ops.pack_wino_weight(self.weight)
+            self._wino_key = key
+        return self._wino
+
     def run_nhwc(self, x, act=ops.ACT_NONE, gdn=None):
         beta = gamma = None
         if gdn is not None:
             beta, gamma = gdn.effective()
+        if self.use_winograd and x.shape[-1] == self.in_channels:
+            return ops.conv3x3_wino_nhwc(x, self.packed_wino(), self.bias, self.out_channels, act, beta, gamma)
         return ops.conv2d_nhwc(x, self.packed(), self.bias, self.out_channels, self.kernel_size,
                                self.stride, act, beta, gamma, cin_real=self.in_channels)
 
@@ -151,6 +171,12 @@ class ConvTranspose2d(_ConvBase):
         return y if self.to_image else ops.nhwc_to_nchw(y)
 
 
+def _f32_image(x):
+    if x.dim() != 4:
+        raise ValueError(f"expected [N,C,H,W], got {tuple(x.shape)}")
+    return x
+
+
 def _to_nhwc(x):
     """NCHW -> NHWC with the channel count padded to a multiple of 8."""
     if x.dim() != 4:
@@ -166,9 +192,32 @@ def _to_nhwc(x):
 class _Chain(nn.Sequential):
     """nn.Sequential whose (conv, GDN|ReLU) pairs run as one fused kernel."""
 
-    def forward_nhwc(self, x, taps=None):
+    def forward_from_image(self, x_nchw, taps=None):
+        """Like forward_nhwc but from an NCHW image: a leading conv(3|4 -> <=128, 3, 1)
+        runs as the dedicated first-layer kernel (K = 9*Cimg, no channel padding)."""
         mods = list(self)
-        i = 0
+        m = mods[0] if mods else None
+        if (isinstance(m, Conv2d) and m.kernel_size == 3 and m.stride == 1 and m.in_channels in (3, 4)
+                and m.out_channels <= 128 and m.out_channels % 4 == 0 and x_nchw.shape[1] == m.in_channels):
+            nxt = mods[1] if len(mods) > 1 else None
+            if isinstance(nxt, GDN) and not nxt.inverse:
+                beta, gamma = nxt.effective()
+                y = ops.conv_first_nchw(x_nchw, m.weight, m.bias, ops.ACT_GDN, beta, gamma)
+                start = 2
+            elif isinstance(nxt, nn.ReLU):
+                y = ops.conv_first_nchw(x_nchw, m.weight, m.bias, ops.ACT_RELU)
+                start = 2
+            else:
+                y = ops.conv_first_nchw(x_nchw, m.weight, m.bias)
+                start = 1
+            if taps is not None:
+                taps.append(y)
+            return self.forward_nhwc(y, taps, start)
+        return self.forward_nhwc(_to_nhwc(x_nchw), taps)
+
+    def forward_nhwc(self, x, taps=None, start=0):
+        mods = list(self)
+        i = start
         while i < len(mods):
             m = mods[i]
             nxt = mods[i + 1] if i + 1 < len(mods) else None
@@ -222,8 +271,11 @@ class AnalysisTransform(nn.Module):
     def forward_nhwc(self, x, taps=None):
         return self.g_a.forward_nhwc(x, taps)
 
+    def forward_from_image(self, x_nchw, taps=None):
+        return self.g_a.forward_from_image(x_nchw, taps)
+
     def forward(self, x):
-        return self.g_a(x)
+        return ops.nhwc_to_nchw(self.g_a.forward_from_image(_f32_image(x)))
 
 
 class SynthesisTransform(nn.Module):

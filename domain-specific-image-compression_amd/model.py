@@ -61,8 +61,7 @@ class CompressionModel(nn.Module):
             raise ValueError(f"expected [N,C,H,W], got {tuple(x.shape)}")
         B, _, H, W = x.shape
         taps = [] if collect_taps else None
-        x_nhwc = _to_nhwc(x)
-        y = self.g_a.forward_nhwc(x_nhwc, taps)            # [B,H/16,W/16,M]
+        y = self.g_a.forward_from_image(x, taps)           # [B,H/16,W/16,M]
         z = self.h_a.forward_nhwc(y, taps)                 # [B,.,.,N]
         y_noisy = z_noisy = None
         if quant_mode == "noise":

@@ -141,6 +141,45 @@ def conv2d_nhwc(x, w_packed, bias, Cout, k, stride, act=ACT_NONE, beta=None, gam
     return out
 
 
+def pack_wino_weight(w: torch.Tensor) -> torch.Tensor:
+    """nn.Conv2d 3x3 weight [Cout,Cin,3,3] -> Winograd-domain U = G g G^T, [16][Cin/8][CoutP][8]."""
+    w = _f32c(w, "pack_wino_weight")
+    Cout, Cin, k, k2 = w.shape
+    if (k, k2) != (3, 3):
+        raise ValueError("pack_wino_weight: kernel must be 3x3")
+    L = _lib.load()
+    dst = torch.empty(L.dsic_wino_weight_floats(Cout, Cin), dtype=torch.float32, device=w.device)
+    _lib.check(L.dsic_pack_wino_weight(_p(w), _p(dst), Cout, Cin, _stream()), "pack_wino_weight")
+    return dst
+
+
+def conv3x3_wino_nhwc(x, u_packed, bias, Cout, act=ACT_NONE, beta=None, gamma=None, out=None):
+    """conv(Cin,Cout,3,1) + fused activation by Winograd F(2x2,3x3) on NHWC activations."""
+    x = _f32c(x, "conv3x3_wino_nhwc")
+    B, H, W, Cin = x.shape
+    if out is None:
+        out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+    L = _lib.load()
+    _timed("conv_wino_kernel", 2.0 * B * H * W * Cout * Cin * 9,
+           lambda: _lib.check(L.dsic_conv3x3_wino_nhwc(_p(x), _p(u_packed), _p(bias), _p(beta), _p(gamma), _p(out),
+                                                       B, H, W, Cin, Cout, act, _stream()), "conv3x3_wino_nhwc"))
+    return out
+
+
+def conv_first_nchw(x, w, bias, act=ACT_NONE, beta=None, gamma=None):
+    """conv(Cimg,Cout,3,1) + fused activation from the NCHW image to NHWC (layers.py:51)."""
+    x = _f32c(x, "conv_first_nchw")
+    w = _f32c(w, "conv_first_nchw")
+    B, C, H, W = x.shape
+    Cout = w.shape[0]
+    out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+    L = _lib.load()
+    _timed(f"conv_first_kernel<{C}>", 2.0 * B * H * W * Cout * C * 9,
+           lambda: _lib.check(L.dsic_conv_first_nchw(_p(x), _p(w), _p(bias), _p(beta), _p(gamma), _p(out), B, C,
+                                                     H, W, Cout, act, _stream()), "conv_first_nchw"))
+    return out
+
+
 def conv_transpose2d_nhwc(x, w_packed, bias, Cout, act=ACT_NONE, beta=None, gamma=None, out=None):
     """ConvTranspose2d(Cin,Cout,5,2,2,output_padding=1) + fused activation."""
     x = _f32c(x, "conv_transpose2d_nhwc")

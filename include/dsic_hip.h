@@ -85,6 +85,28 @@ int dsic_conv2d_nhwc(const float* in, const float* w_packed, const float* bias,
                      int H, int W, int CinP, int Cout, int k, int stride,
                      int act, void* stream);
 
+/* 3x3 stride-1 conv() + optional GDN/IGDN/ReLU by Winograd F(2x2,3x3) on the
+ * fp32 MFMA (layers.py:56,62,67,86,90,94,108,109): 2.25x fewer multiplies than
+ * dsic_conv2d_nhwc, same fp32 operands.  u_packed from dsic_pack_wino_weight
+ * (G g G^T per (cout,cin), [16][Cin/8][CoutP][8]).  Cin % 32 == 0, Cout % 4 == 0,
+ * Cout <= 128.  in NHWC [B,H,W,Cin] -> out NHWC [B,H,W,Cout]. */
+int64_t dsic_wino_weight_floats(int Cout, int Cin);
+int dsic_pack_wino_weight(const float* w_oihw, float* dst, int Cout, int Cin,
+                          void* stream);
+int dsic_conv3x3_wino_nhwc(const float* in, const float* u_packed,
+                           const float* bias, const float* beta,
+                           const float* gamma, float* out, int B, int H, int W,
+                           int Cin, int Cout, int act, void* stream);
+
+/* First analysis layer conv(Cimg,Cout,3,1) + optional GDN/ReLU (layers.py:51)
+ * read straight from the NCHW image [B,Cimg,H,W] (Cimg 3 or 4) with K = 9*Cimg;
+ * w_oihw is the reference weight [Cout,Cimg,3,3] unpacked; out NHWC [B,H,W,Cout],
+ * Cout a multiple of 4, <= 128. */
+int dsic_conv_first_nchw(const float* x_nchw, const float* w_oihw,
+                         const float* bias, const float* beta,
+                         const float* gamma, float* out_nhwc, int B, int Cimg,
+                         int H, int W, int Cout, int act, void* stream);
+
 /* ConvTranspose2d(Cin,Cout,5,2,2,output_padding=1) + optional IGDN/ReLU.
  * in NHWC [B,H,W,Cin] -> out NHWC [B,2H,2W,Cout]. */
 int dsic_conv_transpose2d_nhwc(const float* in, const float* w_packed,

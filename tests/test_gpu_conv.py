@@ -168,3 +168,60 @@ def test_bad_arguments_raise(ops):
         ops.conv2d_nhwc(x, w, b, 8, 3, 1, ops.ACT_GDN)   # GDN without beta/gamma
     with pytest.raises(RuntimeError):
         ops.conv2d_nhwc(x.cpu(), w, b, 8, 3, 1)    # no CPU fallback
+
+
+@pytest.mark.parametrize("B,C,Cout,H,W,act", [(2, 3, 128, 40, 56, "gdn"), (1, 4, 128, 17, 33, "gdn"),
+                                              (1, 3, 64, 8, 16, "none"), (3, 3, 128, 9, 5, "relu")])
+def test_first_layer_kernel_vs_oracle(ops, B, C, Cout, H, W, act):
+    x = _rand((B, C, H, W), 31, 1.0)
+    w = _rand((Cout, C, 3, 3), 32, (C * 9) ** -0.5 * 2)
+    b = _rand((Cout,), 33, 0.5)
+    beta_p = torch.sqrt(0.5 + torch.rand(Cout, generator=torch.Generator().manual_seed(4)) + 2 ** -18)
+    gam_p = torch.sqrt(0.02 + 0.28 * torch.rand(Cout, generator=torch.Generator().manual_seed(5)) + 2 ** -18)
+    ref = O._conv({"p.weight": w, "p.bias": b}, "p", x, 1)
+    code = {"none": ops.ACT_NONE, "gdn": ops.ACT_GDN, "relu": ops.ACT_RELU}[act]
+    if act == "gdn":
+        ref = O.gdn(ref, beta_p, gam_p.view(-1, 1, 1, 1), False)
+    elif act == "relu":
+        ref = torch.relu(ref)
+    y = ops.conv_first_nchw(x.cuda(), w.cuda(), b.cuda(), code, (beta_p ** 2 - 2 ** -18).cuda(),
+                            (gam_p ** 2 - 2 ** -18).cuda())
+    got = ops.nhwc_to_nchw(y).cpu()
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) <= _tol(ref, C * 9) * 4
+
+
+WINO_CASES = [
+    (1, 128, 128, 16, 32, "gdn"),     # exact tiles
+    (2, 128, 128, 19, 37, "igdn"),    # odd sizes: partial Winograd tiles at the borders
+    (1, 192, 128, 16, 16, "relu"),    # h_a.0: 6 chunks
+    (3, 128, 128, 6, 10, "none"),     # fewer pixels than one tile
+    (2, 64, 64, 24, 40, "gdn"),       # half-width column tiles idle
+    (70, 32, 128, 8, 16, "none"),     # more tiles than workgroups on a small box? (persistent loop)
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,act", WINO_CASES)
+def test_winograd_conv_vs_oracle(ops, B, Cin, Cout, H, W, act):
+    x = _rand((B, Cin, H, W), 41, 2.0)
+    w = _rand((Cout, Cin, 3, 3), 42, (Cin * 9) ** -0.5 * 2)
+    b = _rand((Cout,), 43, 0.5)
+    beta_p = torch.sqrt(0.5 + torch.rand(Cout, generator=torch.Generator().manual_seed(4)) + 2 ** -18)
+    gam_p = torch.sqrt(0.02 + 0.28 * torch.rand(Cout, generator=torch.Generator().manual_seed(5)) + 2 ** -18)
+    ref = O._conv({"p.weight": w, "p.bias": b}, "p", x, 1)
+    code = {"none": ops.ACT_NONE, "gdn": ops.ACT_GDN, "igdn": ops.ACT_IGDN, "relu": ops.ACT_RELU}[act]
+    if act in ("gdn", "igdn"):
+        ref = O.gdn(ref, beta_p, gam_p.view(-1, 1, 1, 1), act == "igdn")
+    elif act == "relu":
+        ref = torch.relu(ref)
+    y = ops.conv3x3_wino_nhwc(_nhwc(x).cuda(), ops.pack_wino_weight(w.cuda()), b.cuda(), Cout, code,
+                              (beta_p ** 2 - 2 ** -18).cuda(), (gam_p ** 2 - 2 ** -18).cuda())
+    got = ops.nhwc_to_nchw(y).cpu()
+    assert got.shape == ref.shape
+    err = float((got - ref).abs().max())
+    # Winograd reorders the fp32 sums (transform adds before the products): same tolerance class
+    assert err <= _tol(ref, Cin * 9) * 6, (err, float(ref.abs().max()))
+    # and against float64 the error stays at fp32 level
+    ref64 = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if act == "none":
+        assert float((got.double() - ref64).abs().max()) < 2e-5 * float(ref64.abs().max())

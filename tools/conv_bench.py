@@ -29,7 +29,16 @@ for name, kind, ci, co, h, k, s in LAYERS:
     bias = torch.randn(co, device="cuda")
     beta = torch.rand(co, device="cuda") + 0.5
     gamma = torch.rand(co, device="cuda") * 0.2
-    if kind == "conv":
+    if name == "g_a.0":
+        xi = torch.rand(B, 3, h, h, device="cuda")
+        wr = torch.randn(co, 3, 3, 3, device="cuda") * 0.2
+        f = lambda: ops.conv_first_nchw(xi, wr, bias, ops.ACT_GDN, beta, gamma)
+        flops = 2.0 * B * h * h * co * 27
+    elif kind == "conv" and k == 3 and os.environ.get("DSIC_WINOGRAD", "1") != "0":
+        w = ops.pack_wino_weight(torch.randn(co, ci, 3, 3, device="cuda") * 0.05)
+        f = lambda: ops.conv3x3_wino_nhwc(x, w, bias, co, ops.ACT_GDN, beta, gamma)
+        flops = 2.0 * B * h * h * co * ci * 9
+    elif kind == "conv":
         w = ops.pack_conv_weight(torch.randn(co, ci, k, k, device="cuda") * 0.05)
         f = lambda: ops.conv2d_nhwc(x, w, bias, co, k, s, ops.ACT_GDN, beta, gamma)
         cin_real = 3 if ci == 8 else ci
