@@ -25,6 +25,7 @@ ARCH = "gfx950"
 # differently from their CPU restatements.
 FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
+FLAGS += os.environ.get("DSIC_EXTRA_FLAGS", "").split()   # e.g. -DWINO_RING=1 for A/B builds
 
 
 def _sources():

@@ -104,8 +104,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_kernel(
       const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
       float v = __fadd_rn(acc[m][e], bs);
       if (act == DSIC_ACT_GDN) {
-        const float d = __fsqrt_rn(__fadd_rn(be, __fmul_rn(ga, __fmul_rn(v, v))));
-        v = __fdiv_rn(v, d);
+        v = gdn_apply(v, be, ga, false);
       } else if (act == DSIC_ACT_RELU) {
         v = v > 0.f ? v : 0.f;
       }

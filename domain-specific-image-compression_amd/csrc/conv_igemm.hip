@@ -59,16 +59,8 @@ struct ConvArgs {
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float beta, float gamma) {
-  // Elementwise order of layers.py:21-27: x*x, gamma*that, beta+that, sqrt, div|mul.
-  if (act == DSIC_ACT_GDN) {
-    float d = __fsqrt_rn(__fadd_rn(beta, __fmul_rn(gamma, __fmul_rn(v, v))));
-    return __fdiv_rn(v, d);
-  } else if (act == DSIC_ACT_IGDN) {
-    float d = __fsqrt_rn(__fadd_rn(beta, __fmul_rn(gamma, __fmul_rn(v, v))));
-    return __fmul_rn(v, d);
-  } else if (act == DSIC_ACT_RELU) {
-    return v > 0.f ? v : 0.f;
-  }
+  if (act == DSIC_ACT_GDN || act == DSIC_ACT_IGDN) return gdn_apply(v, beta, gamma, act == DSIC_ACT_IGDN);
+  if (act == DSIC_ACT_RELU) return v > 0.f ? v : 0.f;
   return v;
 }
 

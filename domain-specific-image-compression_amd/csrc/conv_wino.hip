@@ -23,6 +23,10 @@
 // per lane through the LDS transpose.
 #include "common.h"
 
+#ifndef WINO_STAMP
+#define WINO_STAMP 0
+#endif
+
 namespace dsic {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -41,17 +45,20 @@ struct WinoArgs {
 };
 
 __device__ __forceinline__ float wino_act(float v, int act, float beta, float gamma) {
-  if (act == DSIC_ACT_GDN) {
-    const float d = __fsqrt_rn(__fadd_rn(beta, __fmul_rn(gamma, __fmul_rn(v, v))));
-    return __fdiv_rn(v, d);
-  } else if (act == DSIC_ACT_IGDN) {
-    const float d = __fsqrt_rn(__fadd_rn(beta, __fmul_rn(gamma, __fmul_rn(v, v))));
-    return __fmul_rn(v, d);
+  if (act == DSIC_ACT_GDN || act == DSIC_ACT_IGDN) {
+    return gdn_apply(v, beta, gamma, act == DSIC_ACT_IGDN);
   } else if (act == DSIC_ACT_RELU) {
     return v > 0.f ? v : 0.f;
   }
   return v;
 }
+
+#if WINO_STAMP
+__device__ long long wino_stamps[256 * 32];
+#define STAMP(i) if (WINO_STAMP && lane == 0 && wave == stamp_wave && tile_count == 2) wino_stamps[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP(i)
+#endif
 
 constexpr int WCK = 32;                    // channels per chunk
 constexpr int WP = WCK + 4;                // LDS floats per (pos, tile) row
@@ -68,119 +75,141 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
   const int nchunks = Cin / WCK;
   const bool nvalid = nt * 32 < a.CoutP;
   const int wstep = a.CoutP * 8;
-  const int boff = ((nvalid ? nt : 0) * 32 + l31) * 8 + 4 * h;
+  const unsigned boff = (unsigned)((((nvalid ? nt : 0) * 32 + l31) * 8 + 4 * h) * 4);  // bytes
 
   // producer role of this thread: Winograd tile pt, channel quad pq, position half pr
-  const int pt = tid >> 4, pq = (tid >> 1) & 7, pr = tid & 1;
+  const int pt = tid >> 4, pq = tid & 7, pr = (tid >> 3) & 1;  // 8 adjacent lanes = 128 contiguous bytes
   const int ptx = pt & 7, pty = pt >> 3;
   // pr = 0 computes xi in {0,1} from input rows 0,1,2; pr = 1 computes xi in {2,3} from rows 1,2,3
   const int vwrite = ((pr * 8) * 32 + pt) * WP + 4 * pq;  // + (xi_local*4 + nu)*32*WP
 
   floatx4 raw[12];
   int cur_tile = blockIdx.x;
-  // ---- producer: issue the loads of (tile, chunk) -----------------------------------------
-  auto issue = [&](int tile, int chunk) {
+  // ---- producer: the 3x4 pixel patch of (tile, chunk) this thread loads ---------------------
+  // Loads are issued ONE AT A TIME between MFMA clusters (vmcnt retires in order: a burst of
+  // 12 loads in front of the U-fragment loads would stall the first cluster of every chunk
+  // for a full memory latency).  Out-of-image pixels load a clamped address and are zeroed
+  // in the transform, so the load itself is branch-free.
+  int ld_gy0 = 0, ld_gx0 = 0;
+  bool ld_border = true;  // the 18x10 window of the aimed tile leaves the image somewhere
+  const char* ld_base = (const char*)a.in;  // wave-uniform: image + chunk; lanes add a 32-bit byte offset
+  auto aim = [&](int tile, int chunk) {
     const int tx = tile % a.tiles_x;
     const int ty = (tile / a.tiles_x) % a.tiles_y;
     const int n = tile / (a.tiles_x * a.tiles_y);
-    const int gy0 = ty * 8 + 2 * pty - 1 + pr, gx0 = tx * 16 + 2 * ptx - 1;
-    const float* base = a.in + (size_t)n * a.H * a.W * Cin + chunk * WCK + 4 * pq;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int gy = gy0 + i, gx = gx0 + j;
-        floatx4 v = {0.f, 0.f, 0.f, 0.f};
-        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-          v = *(const floatx4*)(base + ((size_t)gy * a.W + gx) * Cin);
-        raw[i * 4 + j] = v;
-      }
+    ld_border = ty == 0 || tx == 0 || ty * 8 + 9 > a.H || tx * 16 + 17 > a.W;
+    ld_gy0 = ty * 8 + 2 * pty - 1 + pr;
+    ld_gx0 = tx * 16 + 2 * ptx - 1;
+    ld_base = (const char*)(a.in + (size_t)n * a.H * a.W * Cin + chunk * WCK);
   };
-  // ---- producer: B^T d B for this thread's two xi rows, write to V buffer -----------------
-  auto transform = [&](float* vbuf) {
-    floatx4 t[2][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (pr == 0) {
-        t[0][j] = raw[0 * 4 + j] - raw[2 * 4 + j];  // xi0 = d0 - d2
-        t[1][j] = raw[1 * 4 + j] + raw[2 * 4 + j];  // xi1 = d1 + d2
-      } else {                                      // local rows are d1,d2,d3
-        t[0][j] = raw[1 * 4 + j] - raw[0 * 4 + j];  // xi2 = d2 - d1
-        t[1][j] = raw[0 * 4 + j] - raw[2 * 4 + j];  // xi3 = d1 - d3
+  auto load_one = [&](int k) {
+    int gy = ld_gy0 + (k >> 2), gx = ld_gx0 + (k & 3);
+    gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+    gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+    const unsigned off = (unsigned)(((gy * a.W + gx) * Cin + 4 * pq) * 4);
+    raw[k] = *(const floatx4*)(ld_base + off);
+  };
+  // ---- producer: B^T d B for this thread's two xi rows, in 8 pieces that are issued between
+  // MFMA clusters (VALU and LDS writes ride in the shadow of the 64-cycle MFMAs) ---------------
+  floatx4 tr[2][4];
+  auto transform_piece = [&](int piece, float* vbuf) {
+    if (piece < 4) {  // row combination of window column j = piece
+      const int j = piece;
+      floatx4 r0 = raw[0 * 4 + j], r1 = raw[1 * 4 + j], r2 = raw[2 * 4 + j];
+      if (ld_border) {
+        const int gx = ld_gx0 + j;
+        const bool xok = gx >= 0 && gx < a.W;
+        const floatx4 z = {0.f, 0.f, 0.f, 0.f};
+        if (!(xok && ld_gy0 >= 0 && ld_gy0 < a.H)) r0 = z;
+        if (!(xok && ld_gy0 + 1 >= 0 && ld_gy0 + 1 < a.H)) r1 = z;
+        if (!(xok && ld_gy0 + 2 >= 0 && ld_gy0 + 2 < a.H)) r2 = z;
       }
-    }
-#pragma unroll
-    for (int x = 0; x < 2; ++x) {
-      const floatx4 v0 = t[x][0] - t[x][2];
-      const floatx4 v1 = t[x][1] + t[x][2];
-      const floatx4 v2 = t[x][2] - t[x][1];
-      const floatx4 v3 = t[x][1] - t[x][3];
+      if (pr == 0) {
+        tr[0][j] = r0 - r2;  // xi0 = d0 - d2
+        tr[1][j] = r1 + r2;  // xi1 = d1 + d2
+      } else {               // local rows are d1,d2,d3
+        tr[0][j] = r1 - r0;  // xi2 = d2 - d1
+        tr[1][j] = r0 - r2;  // xi3 = d1 - d3
+      }
+    } else {  // column combination: pieces 4,5 -> x=0 (nu 0,1 / 2,3); 6,7 -> x=1
+      const int x = (piece - 4) >> 1, half = (piece - 4) & 1;
       float* dst = vbuf + vwrite + (x * 4) * 32 * WP;
-      *(floatx4*)(dst + 0 * 32 * WP) = v0;
-      *(floatx4*)(dst + 1 * 32 * WP) = v1;
-      *(floatx4*)(dst + 2 * 32 * WP) = v2;
-      *(floatx4*)(dst + 3 * 32 * WP) = v3;
+      if (half == 0) {
+        *(floatx4*)(dst + 0 * 32 * WP) = tr[x][0] - tr[x][2];
+        *(floatx4*)(dst + 1 * 32 * WP) = tr[x][1] + tr[x][2];
+      } else {
+        *(floatx4*)(dst + 2 * 32 * WP) = tr[x][2] - tr[x][1];
+        *(floatx4*)(dst + 3 * 32 * WP) = tr[x][1] - tr[x][3];
+      }
     }
   };
 
   floatx16 acc[8];
+  int tile_count = 0;
+  const int stamp_wave = 0;
+  (void)tile_count; (void)stamp_wave;
   const int aread = ((ph * 8) * 32 + l31) * WP + 4 * h;  // + p*32*WP + sub*8
 
   if (cur_tile < a.ntiles) {
-    issue(cur_tile, 0);
-    transform(lds);
+    aim(cur_tile, 0);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) load_one(k);
+#pragma unroll
+    for (int piece = 0; piece < 8; ++piece) transform_piece(piece, lds);
     __syncthreads();
   }
   int buf = 0;
+  floatx4 Bq[4];
+#pragma unroll
+  for (int f = 0; f < 3; ++f)
+    Bq[f] = *(const floatx4*)((const char*)(a.u + (size_t)((ph * 8 + f) * Cin8) * wstep) + boff);
+  Bq[3] = Bq[0];
   while (cur_tile < a.ntiles) {
 #pragma unroll
     for (int p = 0; p < 8; ++p)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
     const int next_tile = cur_tile + gridDim.x;
+    tile_count++;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-      // prefetch the raw input of the next (tile, chunk)
+      STAMP(chunk * 4 + 0);
+      // aim the producer at the next (tile, chunk); past the end it re-reads valid data
       const bool last = chunk + 1 == nchunks;
       const bool have_next = !last || next_tile < a.ntiles;
-      if (have_next) issue(last ? next_tile : cur_tile, last ? 0 : chunk + 1);
-      // consumer: 8 positions x 4 sub-chunks x 4 k-steps
+      aim(last ? (next_tile < a.ntiles ? next_tile : cur_tile) : cur_tile, last ? 0 : chunk + 1);
+      // consumer: 8 positions x 4 sub-chunks x 4 k-steps.  U fragments run in a 4-deep
+      // register ring three steps ahead (L2 latency), continuous across chunks and tiles
+      // (U does not depend on the tile); V fragments one step ahead (LDS latency).
       const float* vb = lds + buf * WBUF + aread;
-      const float* ub = a.u + (size_t)(chunk * 4) * wstep + boff;
-      floatx4 A0, B0, A1, B1;
-      A0 = *(const floatx4*)(vb);
-      B0 = *(const floatx4*)(ub + (size_t)((ph * 8) * Cin8) * wstep);
+      const float* ub = a.u + (size_t)(chunk * 4) * wstep;
+      const float* ubn = a.u + (size_t)((chunk + 1 == nchunks ? 0 : chunk + 1) * 4) * wstep;
+      floatx4 Aq[2];
+      Aq[0] = *(const floatx4*)(vb);
 #pragma unroll
-      for (int it = 0; it < 32; it += 2) {  // it = sub*8 + p
+      for (int it = 0; it < 32; ++it) {  // it = sub*8 + p
         {
+          const int f = it + 3;  // U fragment to fetch now
+          const int fp = f & 7, fs = (f >> 3) & 3;
+          const float* src = (f < 32 ? ub : ubn) + (size_t)((ph * 8 + fp) * Cin8 + fs) * wstep;  // uniform
+          Bq[f & 3] = *(const floatx4*)((const char*)src + boff);
+        }
+        if (it < 12) load_one(it);  // producer loads first: they are consumed from step 20 on
+        if (it + 1 < 32) {
           const int p1 = (it + 1) & 7, s1 = (it + 1) >> 3;
-          A1 = *(const floatx4*)(vb + p1 * 32 * WP + s1 * 8);
-          B1 = *(const floatx4*)(ub + (size_t)((ph * 8 + p1) * Cin8 + s1) * wstep);
+          Aq[(it + 1) & 1] = *(const floatx4*)(vb + p1 * 32 * WP + s1 * 8);
         }
-        {
-          const int p0 = it & 7;
-          __builtin_amdgcn_s_setprio(1);
+        const int p0 = it & 7;
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-          for (int s = 0; s < 4; ++s)
-            acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[s], B0[s], acc[p0], 0, 0, 0);
-          __builtin_amdgcn_s_setprio(0);
-        }
-        if (it + 2 < 32) {
-          const int p2 = (it + 2) & 7, s2 = (it + 2) >> 3;
-          A0 = *(const floatx4*)(vb + p2 * 32 * WP + s2 * 8);
-          B0 = *(const floatx4*)(ub + (size_t)((ph * 8 + p2) * Cin8 + s2) * wstep);
-        }
-        {
-          const int p1 = (it + 1) & 7;
-          __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-          for (int s = 0; s < 4; ++s)
-            acc[p1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[s], B1[s], acc[p1], 0, 0, 0);
-          __builtin_amdgcn_s_setprio(0);
-        }
+        for (int s = 0; s < 4; ++s)
+          acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aq[it & 1][s], Bq[it & 3][s], acc[p0], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (it >= 20 && it < 28 && have_next) transform_piece(it - 20, lds + (buf ^ 1) * WBUF);
       }
-      // producer: transform the prefetched chunk into the other buffer
-      if (have_next) transform(lds + (buf ^ 1) * WBUF);
+      STAMP(chunk * 4 + 1);
+      STAMP(chunk * 4 + 2);
       __syncthreads();
+      STAMP(chunk * 4 + 3);
       buf ^= 1;
     }
 
@@ -189,6 +218,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
     //   N[.][0] = M0 + M1 + M2,  N[.][1] = M1 - M2 - M3.
     // Y[i][j] = (A^T N)[i][j]:  Y[0] = N0 + N1 + N2,  Y[1] = N1 - N2 - N3.
     // ph=0 finishes row i=0 and needs N2 from ph=1; ph=1 finishes i=1 and needs N1 from ph=0.
+    STAMP(24);
     floatx16 n0[2], n1[2];  // [j] for local xi 0 and 1
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -224,6 +254,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
         }
     }
     __syncthreads();  // exchange area free again (it is the next chunk's transform target)
+    STAMP(25);
 
     if (nvalid) {
       const int tx = cur_tile % a.tiles_x;
@@ -263,7 +294,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
         __builtin_amdgcn_wave_barrier();
       }
     }
+    STAMP(26);
     __syncthreads();  // transpose patches done before the next tile's producers reuse the area
+    STAMP(27);
     cur_tile = next_tile;
   }
 }
@@ -301,6 +334,12 @@ __global__ void pack_wino_weight_kernel(const float* __restrict__ w, float* __re
 }  // namespace dsic
 
 using namespace dsic;
+
+#if WINO_STAMP
+extern "C" int dsic_debug_wino_stamps(long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(wino_stamps), sizeof(long long) * 256 * 32) == hipSuccess ? 0 : 2;
+}
+#endif
 
 extern "C" int64_t dsic_wino_weight_floats(int Cout, int Cin) {
   return (int64_t)16 * (round_up(Cin, 8) / 8) * round_up(Cout, 32) * 8;
