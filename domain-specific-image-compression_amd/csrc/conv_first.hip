@@ -19,7 +19,7 @@ template <int C>
 __global__ __launch_bounds__(256, 2) void conv_first_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ beta, const float* __restrict__ gamma, float* __restrict__ out, int B,
-    int H, int W, int Cout, int act, int tiles_x, int tiles_y) {
+    int H, int W, int Cout, int act, int tiles_x, int tiles_y, int s2d) {
   constexpr int K = 9 * C;
   constexpr int KP = (K + 1) / 2 * 2;  // even
   constexpr int NS = KP / 2;           // MFMA k-steps
@@ -120,8 +120,13 @@ __global__ __launch_bounds__(256, 2) void conv_first_kernel(
       const floatx4 v = *(const floatx4*)(epi + rr * EPI_STRIDE + c4);
       const int r = m * 32 + rr;
       const int ox = ox0 + r % TW, oy = oy0 + r / TW;
-      if (oy < H && ox < W && nn < Cout)
-        *(floatx4*)(out + (((size_t)n * H + oy) * W + ox) * Cout + nn) = v;
+      if (oy < H && ox < W && nn < Cout) {
+        // s2d: pixel (oy,ox) becomes channel block (oy&1)*2+(ox&1) of pixel (oy/2,ox/2)
+        const size_t o = s2d ? (((size_t)n * (H >> 1) + (oy >> 1)) * (W >> 1) + (ox >> 1)) * (4 * Cout) +
+                                   ((oy & 1) * 2 + (ox & 1)) * Cout + nn
+                             : (((size_t)n * H + oy) * W + ox) * Cout + nn;
+        *(floatx4*)(out + o) = v;
+      }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
@@ -136,21 +141,22 @@ using namespace dsic;
 // (layers.py:51).  w is the REFERENCE weight tensor [Cout][Cimg][3][3], unpacked.
 extern "C" int dsic_conv_first_nchw(const float* x_nchw, const float* w_oihw, const float* bias,
                                     const float* beta, const float* gamma, float* out_nhwc, int B,
-                                    int Cimg, int H, int W, int Cout, int act, void* stream) {
+                                    int Cimg, int H, int W, int Cout, int act, int s2d, void* stream) {
   DSIC_REQUIRE(x_nchw && w_oihw && bias && out_nhwc, "conv_first: null pointer");
   DSIC_REQUIRE(B > 0 && H > 0 && W > 0, "conv_first: empty tensor");
   DSIC_REQUIRE(Cimg == 3 || Cimg == 4, "conv_first: Cimg=%d must be 3 or 4", Cimg);
   DSIC_REQUIRE(Cout > 0 && Cout <= 128 && Cout % 4 == 0, "conv_first: Cout=%d must be a multiple of 4, <= 128", Cout);
   DSIC_REQUIRE(act == DSIC_ACT_NONE || act == DSIC_ACT_GDN || act == DSIC_ACT_RELU, "conv_first: act=%d", act);
   DSIC_REQUIRE(act != DSIC_ACT_GDN || (beta && gamma), "conv_first: GDN needs beta and gamma");
+  DSIC_REQUIRE(!s2d || (H % 2 == 0 && W % 2 == 0), "conv_first: space-to-depth output needs even H and W");
   const int tx = ceil_div(W, 16), ty = ceil_div(H, 8);
   DSIC_REQUIRE((int64_t)tx * ty * B < ((int64_t)1 << 31), "conv_first: grid too large");
   dim3 grid(tx * ty * B), block(256);
   if (Cimg == 3)
     hipLaunchKernelGGL(conv_first_kernel<3>, grid, block, 0, (hipStream_t)stream, x_nchw, w_oihw, bias, beta,
-                       gamma, out_nhwc, B, H, W, Cout, act, tx, ty);
+                       gamma, out_nhwc, B, H, W, Cout, act, tx, ty, s2d);
   else
     hipLaunchKernelGGL(conv_first_kernel<4>, grid, block, 0, (hipStream_t)stream, x_nchw, w_oihw, bias, beta,
-                       gamma, out_nhwc, B, H, W, Cout, act, tx, ty);
+                       gamma, out_nhwc, B, H, W, Cout, act, tx, ty, s2d);
   return check_launch("conv_first");
 }

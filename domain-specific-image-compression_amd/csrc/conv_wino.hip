@@ -41,6 +41,7 @@ struct WinoArgs {
   float* out;
   int B, H, W, Cin, Cout, CoutP;
   int act;
+  int s2d;  // store space-to-depth: [B,H/2,W/2,4*Cout] (feeds a 5x5/s2 layer run as 3x3 over 4*C)
   int tiles_x, tiles_y, ntiles;  // 16x8-pixel output tiles
 };
 
@@ -287,8 +288,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
           const floatx4 v = *(const floatx4*)(epi + rr * 36 + c4);
           const int oy = ty * 8 + 2 * (rr >> 3) + ph;
           const int ox = tx * 16 + 2 * (rr & 7) + j;
-          if (oy < a.H && ox < a.W && nn < a.Cout)
-            *(floatx4*)(a.out + (((size_t)n * a.H + oy) * a.W + ox) * a.Cout + nn) = v;
+          if (oy < a.H && ox < a.W && nn < a.Cout) {
+            const size_t o = a.s2d ? (((size_t)n * (a.H >> 1) + (oy >> 1)) * (a.W >> 1) + (ox >> 1)) * (4 * a.Cout) +
+                                         ((oy & 1) * 2 + (ox & 1)) * a.Cout + nn
+                                   : (((size_t)n * a.H + oy) * a.W + ox) * a.Cout + nn;
+            *(floatx4*)(a.out + o) = v;
+          }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
@@ -302,8 +307,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
 }
 
 // U_p = G g G^T per (cout, cin), packed [16][Cin/8][CoutP][8].
+// s2 = 0: g is the 3x3 kernel of a stride-1 conv, w [Cout][Cin][3][3].
+// s2 = 1: w [Cout][Cs][5][5] is a 5x5 stride-2 pad-2 kernel; over the space-to-depth input
+//         (channel c' = (a*2+b)*Cs + c holds x[2i+a][2j+b][c]) it is the 3x3 stride-1 kernel
+//         g_ab[u][v] = w[2u+a][2v+b] (zero where 2u+a or 2v+b exceeds 4): Cin = 4*Cs.
 __global__ void pack_wino_weight_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout,
-                                        int Cin, int Cin8, int CoutP, int64_t total) {
+                                        int Cin, int Cin8, int CoutP, int s2, int64_t total) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int j = i & 7;
@@ -316,7 +325,23 @@ __global__ void pack_wino_weight_kernel(const float* __restrict__ w, float* __re
   const int c = c8 * 8 + j;
   float v = 0.f;
   if (n < Cout && c < Cin) {
-    const float* g = w + ((size_t)n * Cin + c) * 9;
+    float g[9];
+    if (!s2) {
+      const float* gp = w + ((size_t)n * Cin + c) * 9;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) g[t] = gp[t];
+    } else {
+      const int Cs = Cin >> 2, ab = c / Cs, cs = c % Cs;
+      const int pa = ab >> 1, pb = ab & 1;
+      const float* gp = w + ((size_t)n * Cs + cs) * 25;
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+          const int ky = 2 * u + pa, kx = 2 * v + pb;
+          g[u * 3 + v] = (ky < 5 && kx < 5) ? gp[ky * 5 + kx] : 0.f;
+        }
+    }
     // row combination (G g)[xi][kx], then column combination with G^T
     float row[3];
 #pragma unroll
@@ -350,13 +375,22 @@ extern "C" int dsic_pack_wino_weight(const float* w_oihw, float* dst, int Cout, 
   const int Cin8 = round_up(Cin, 8) / 8, CoutP = round_up(Cout, 32);
   const int64_t total = dsic_wino_weight_floats(Cout, Cin);
   hipLaunchKernelGGL(pack_wino_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, w_oihw, dst, Cout, Cin, Cin8, CoutP, total);
+                     (hipStream_t)stream, w_oihw, dst, Cout, Cin, Cin8, CoutP, 0, total);
   return check_launch("pack_wino_weight");
+}
+
+extern "C" int dsic_pack_wino_s2_weight(const float* w_oihw5, float* dst, int Cout, int Cs, void* stream) {
+  DSIC_REQUIRE(w_oihw5 && dst && Cout > 0 && Cs > 0 && Cs % 8 == 0, "pack_wino_s2_weight: bad argument");
+  const int Cin = 4 * Cs, Cin8 = Cin / 8, CoutP = round_up(Cout, 32);
+  const int64_t total = dsic_wino_weight_floats(Cout, Cin);
+  hipLaunchKernelGGL(pack_wino_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, w_oihw5, dst, Cout, Cin, Cin8, CoutP, 1, total);
+  return check_launch("pack_wino_s2_weight");
 }
 
 extern "C" int dsic_conv3x3_wino_nhwc(const float* in, const float* u_packed, const float* bias,
                                       const float* beta, const float* gamma, float* out, int B, int H,
-                                      int W, int Cin, int Cout, int act, void* stream) {
+                                      int W, int Cin, int Cout, int act, int s2d_out, void* stream) {
   DSIC_REQUIRE(in && u_packed && bias && out, "conv3x3_wino: null pointer");
   DSIC_REQUIRE(B > 0 && H > 0 && W > 0, "conv3x3_wino: empty tensor");
   DSIC_REQUIRE(Cin > 0 && Cin % 32 == 0, "conv3x3_wino: Cin=%d must be a positive multiple of 32", Cin);
@@ -365,7 +399,9 @@ extern "C" int dsic_conv3x3_wino_nhwc(const float* in, const float* u_packed, co
   DSIC_REQUIRE(!(act == DSIC_ACT_GDN || act == DSIC_ACT_IGDN) || (beta && gamma), "conv3x3_wino: GDN needs beta and gamma");
   WinoArgs a{};
   a.in = in; a.u = u_packed; a.bias = bias; a.beta = beta; a.gamma = gamma; a.out = out;
+  DSIC_REQUIRE(!s2d_out || (H % 2 == 0 && W % 2 == 0), "conv3x3_wino: space-to-depth output needs even H and W");
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.CoutP = round_up(Cout, 32); a.act = act;
+  a.s2d = s2d_out;
   a.tiles_x = ceil_div(W, 16); a.tiles_y = ceil_div(H, 8);
   const int64_t nt = (int64_t)a.tiles_x * a.tiles_y * B;
   DSIC_REQUIRE(nt < ((int64_t)1 << 31), "conv3x3_wino: too many tiles");

@@ -108,21 +108,41 @@ class Conv2d(_ConvBase):
         return (USE_WINOGRAD and self.kernel_size == 3 and self.stride == 1 and self.in_channels % 32 == 0
                 and self.out_channels % 4 == 0 and 64 <= self.out_channels <= 128)
 
+    @property
+    def use_winograd_s2(self):
+        """5x5 stride-2 layers run as a 3x3 Winograd conv over the space-to-depth input (4*Cin
+        channels) when the producing layer can write that layout."""
+        return (USE_WINOGRAD and self.kernel_size == 5 and self.stride == 2 and self.in_channels % 8 == 0
+                and self.out_channels % 4 == 0 and 64 <= self.out_channels <= 128)
+
     def packed_wino(self):
         key = self._key()
         if getattr(self, "_wino", None) is None or self._wino_key != key:
-            self._wino = ops.pack_wino_weight(self.weight)
+            self._wino = (ops.pack_wino_s2_weight(self.weight) if self.kernel_size == 5
+                          else ops.pack_wino_weight(self.weight))
             self._wino_key = key
         return self._wino
 
-    def run_nhwc(self, x, act=ops.ACT_NONE, gdn=None):
+    def run_nhwc(self, x, act=ops.ACT_NONE, gdn=None, x_is_s2d=False, s2d_out=False):
+        """x_is_s2d: x is the space-to-depth image of this layer's input; s2d_out: write the
+        output space-to-depth (only the Winograd paths can)."""
         beta = gamma = None
         if gdn is not None:
             beta, gamma = gdn.effective()
+        if x_is_s2d:
+            B, H2, W2, _ = x.shape
+            return ops.conv3x3_wino_nhwc(x, self.packed_wino(), self.bias, self.out_channels, act, beta, gamma,
+                                         s2d_out=s2d_out,
+                                         algo_flops=2.0 * B * H2 * W2 * self.out_channels * self.in_channels * 25)
         if self.use_winograd and x.shape[-1] == self.in_channels:
-            return ops.conv3x3_wino_nhwc(x, self.packed_wino(), self.bias, self.out_channels, act, beta, gamma)
+            return ops.conv3x3_wino_nhwc(x, self.packed_wino(), self.bias, self.out_channels, act, beta, gamma,
+                                         s2d_out=s2d_out)
+        assert not s2d_out
         return ops.conv2d_nhwc(x, self.packed(), self.bias, self.out_channels, self.kernel_size,
                                self.stride, act, beta, gamma, cin_real=self.in_channels)
+
+    def can_write_s2d(self, x_is_s2d):
+        return x_is_s2d or self.use_winograd
 
     @torch.no_grad()
     def forward(self, x):
@@ -192,6 +212,13 @@ def _to_nhwc(x):
 class _Chain(nn.Sequential):
     """nn.Sequential whose (conv, GDN|ReLU) pairs run as one fused kernel."""
 
+    @staticmethod
+    def _wants_s2d(mods, j, H, W):
+        """Does the conv that consumes the output of the layer ending before index j take
+        space-to-depth input?  (H, W: spatial size of that output.)"""
+        nxt = mods[j] if j < len(mods) else None
+        return isinstance(nxt, Conv2d) and nxt.use_winograd_s2 and H % 2 == 0 and W % 2 == 0
+
     def forward_from_image(self, x_nchw, taps=None):
         """Like forward_nhwc but from an NCHW image: a leading conv(3|4 -> <=128, 3, 1)
         runs as the dedicated first-layer kernel (K = 9*Cimg, no channel padding)."""
@@ -200,28 +227,49 @@ class _Chain(nn.Sequential):
         if (isinstance(m, Conv2d) and m.kernel_size == 3 and m.stride == 1 and m.in_channels in (3, 4)
                 and m.out_channels <= 128 and m.out_channels % 4 == 0 and x_nchw.shape[1] == m.in_channels):
             nxt = mods[1] if len(mods) > 1 else None
+            H, W = x_nchw.shape[2], x_nchw.shape[3]
             if isinstance(nxt, GDN) and not nxt.inverse:
                 beta, gamma = nxt.effective()
-                y = ops.conv_first_nchw(x_nchw, m.weight, m.bias, ops.ACT_GDN, beta, gamma)
+                s2d = self._wants_s2d(mods, 2, H, W)
+                y = ops.conv_first_nchw(x_nchw, m.weight, m.bias, ops.ACT_GDN, beta, gamma, s2d_out=s2d)
                 start = 2
             elif isinstance(nxt, nn.ReLU):
-                y = ops.conv_first_nchw(x_nchw, m.weight, m.bias, ops.ACT_RELU)
+                s2d = self._wants_s2d(mods, 2, H, W)
+                y = ops.conv_first_nchw(x_nchw, m.weight, m.bias, ops.ACT_RELU, s2d_out=s2d)
                 start = 2
             else:
-                y = ops.conv_first_nchw(x_nchw, m.weight, m.bias)
+                s2d = self._wants_s2d(mods, 1, H, W)
+                y = ops.conv_first_nchw(x_nchw, m.weight, m.bias, s2d_out=s2d)
                 start = 1
             if taps is not None:
-                taps.append(y)
-            return self.forward_nhwc(y, taps, start)
+                taps.append(ops.depth_to_space(y) if s2d else y)
+            return self.forward_nhwc(y, taps, start, x_is_s2d=s2d)
         return self.forward_nhwc(_to_nhwc(x_nchw), taps)
 
-    def forward_nhwc(self, x, taps=None, start=0):
+    def forward_nhwc(self, x, taps=None, start=0, x_is_s2d=False):
         mods = list(self)
         i = start
         while i < len(mods):
             m = mods[i]
             nxt = mods[i + 1] if i + 1 < len(mods) else None
-            if isinstance(m, (Conv2d, ConvTranspose2d)):
+            out_s2d = False
+            if isinstance(m, Conv2d):
+                fused = isinstance(nxt, (GDN, nn.ReLU))
+                # spatial size of this layer's output
+                if x_is_s2d:
+                    Ho, Wo = x.shape[1], x.shape[2]
+                else:
+                    Ho, Wo = -(-x.shape[1] // m.stride), -(-x.shape[2] // m.stride)
+                out_s2d = m.can_write_s2d(x_is_s2d) and self._wants_s2d(mods, i + (2 if fused else 1), Ho, Wo)
+                if isinstance(nxt, GDN):
+                    x = m.run_nhwc(x, ops.ACT_IGDN if nxt.inverse else ops.ACT_GDN, nxt, x_is_s2d, out_s2d)
+                elif isinstance(nxt, nn.ReLU):
+                    x = m.run_nhwc(x, ops.ACT_RELU, None, x_is_s2d, out_s2d)
+                else:
+                    x = m.run_nhwc(x, ops.ACT_NONE, None, x_is_s2d, out_s2d)
+                i += 2 if fused else 1
+            elif isinstance(m, ConvTranspose2d):
+                assert not x_is_s2d
                 if isinstance(nxt, GDN):
                     x = m.run_nhwc(x, ops.ACT_IGDN if nxt.inverse else ops.ACT_GDN, nxt)
                     i += 2
@@ -232,6 +280,7 @@ class _Chain(nn.Sequential):
                     x = m.run_nhwc(x)
                     i += 1
             elif isinstance(m, GDN):
+                assert not x_is_s2d
                 x = ops.nchw_to_nhwc(m(ops.nhwc_to_nchw(x)))
                 i += 1
             elif isinstance(m, nn.ReLU):
@@ -239,8 +288,10 @@ class _Chain(nn.Sequential):
                 i += 1
             else:  # pragma: no cover
                 raise TypeError(f"unsupported module {type(m).__name__}")
+            x_is_s2d = out_s2d
             if taps is not None:
-                taps.append(x)
+                taps.append(ops.depth_to_space(x) if x_is_s2d else x)
+        assert not x_is_s2d
         return x
 
     @torch.no_grad()

@@ -153,30 +153,61 @@ def pack_wino_weight(w: torch.Tensor) -> torch.Tensor:
     return dst
 
 
-def conv3x3_wino_nhwc(x, u_packed, bias, Cout, act=ACT_NONE, beta=None, gamma=None, out=None):
-    """conv(Cin,Cout,3,1) + fused activation by Winograd F(2x2,3x3) on NHWC activations."""
+def pack_wino_s2_weight(w: torch.Tensor) -> torch.Tensor:
+    """5x5 stride-2 weight [Cout,Cs,5,5] -> Winograd U of the equivalent 3x3 conv over 4*Cs s2d channels."""
+    w = _f32c(w, "pack_wino_s2_weight")
+    Cout, Cs, k, k2 = w.shape
+    if (k, k2) != (5, 5):
+        raise ValueError("pack_wino_s2_weight: kernel must be 5x5")
+    L = _lib.load()
+    dst = torch.empty(L.dsic_wino_weight_floats(Cout, 4 * Cs), dtype=torch.float32, device=w.device)
+    _lib.check(L.dsic_pack_wino_s2_weight(_p(w), _p(dst), Cout, Cs, _stream()), "pack_wino_s2_weight")
+    return dst
+
+
+def space_to_depth(x_nhwc):
+    """[B,H,W,C] -> [B,H/2,W/2,4C] with channel (a*2+b)*C+c = x[2i+a][2j+b][c] (layout plumbing)."""
+    B, H, W, C = x_nhwc.shape
+    return x_nhwc.view(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H // 2, W // 2, 4 * C).contiguous()
+
+
+def depth_to_space(x_s2d):
+    B, H2, W2, C4 = x_s2d.shape
+    C = C4 // 4
+    return x_s2d.view(B, H2, W2, 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * H2, 2 * W2, C).contiguous()
+
+
+def conv3x3_wino_nhwc(x, u_packed, bias, Cout, act=ACT_NONE, beta=None, gamma=None, out=None, s2d_out=False,
+                      algo_flops=None):
+    """conv(Cin,Cout,3,1) + fused activation by Winograd F(2x2,3x3) on NHWC activations.
+
+    s2d_out: write [B,H/2,W/2,4*Cout] (space-to-depth) for a following 5x5/s2 layer."""
     x = _f32c(x, "conv3x3_wino_nhwc")
     B, H, W, Cin = x.shape
     if out is None:
-        out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+        shape = (B, H // 2, W // 2, 4 * Cout) if s2d_out else (B, H, W, Cout)
+        out = torch.empty(shape, dtype=torch.float32, device=x.device)
     L = _lib.load()
-    _timed("conv_wino_kernel", 2.0 * B * H * W * Cout * Cin * 9,
+    _timed("conv_wino_kernel", algo_flops if algo_flops is not None else 2.0 * B * H * W * Cout * Cin * 9,
            lambda: _lib.check(L.dsic_conv3x3_wino_nhwc(_p(x), _p(u_packed), _p(bias), _p(beta), _p(gamma), _p(out),
-                                                       B, H, W, Cin, Cout, act, _stream()), "conv3x3_wino_nhwc"))
+                                                       B, H, W, Cin, Cout, act, int(bool(s2d_out)), _stream()),
+                              "conv3x3_wino_nhwc"))
     return out
 
 
-def conv_first_nchw(x, w, bias, act=ACT_NONE, beta=None, gamma=None):
+def conv_first_nchw(x, w, bias, act=ACT_NONE, beta=None, gamma=None, s2d_out=False):
     """conv(Cimg,Cout,3,1) + fused activation from the NCHW image to NHWC (layers.py:51)."""
     x = _f32c(x, "conv_first_nchw")
     w = _f32c(w, "conv_first_nchw")
     B, C, H, W = x.shape
     Cout = w.shape[0]
-    out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+    shape = (B, H // 2, W // 2, 4 * Cout) if s2d_out else (B, H, W, Cout)
+    out = torch.empty(shape, dtype=torch.float32, device=x.device)
     L = _lib.load()
     _timed(f"conv_first_kernel<{C}>", 2.0 * B * H * W * Cout * C * 9,
            lambda: _lib.check(L.dsic_conv_first_nchw(_p(x), _p(w), _p(bias), _p(beta), _p(gamma), _p(out), B, C,
-                                                     H, W, Cout, act, _stream()), "conv_first_nchw"))
+                                                     H, W, Cout, act, int(bool(s2d_out)), _stream()),
+                              "conv_first_nchw"))
     return out
 
 

@@ -96,16 +96,26 @@ int dsic_pack_wino_weight(const float* w_oihw, float* dst, int Cout, int Cin,
 int dsic_conv3x3_wino_nhwc(const float* in, const float* u_packed,
                            const float* bias, const float* beta,
                            const float* gamma, float* out, int B, int H, int W,
-                           int Cin, int Cout, int act, void* stream);
+                           int Cin, int Cout, int act, int s2d_out, void* stream);
+/* conv(Cs,Cout,5,2) (layers.py:54,60,65) as a 3x3 stride-1 Winograd conv over the
+ * space-to-depth input [B,H/2,W/2,4*Cs] (channel (a*2+b)*Cs+c = x[2i+a][2j+b][c],
+ * written by the producing layer when its s2d_out flag is set): 16 instead of
+ * 25 multiplies per output and channel pair.  Pack the reference [Cout,Cs,5,5]
+ * weight with dsic_pack_wino_s2_weight and call dsic_conv3x3_wino_nhwc with
+ * Cin = 4*Cs on the half-resolution grid. */
+int dsic_pack_wino_s2_weight(const float* w_oihw5, float* dst, int Cout, int Cs,
+                             void* stream);
 
 /* First analysis layer conv(Cimg,Cout,3,1) + optional GDN/ReLU (layers.py:51)
  * read straight from the NCHW image [B,Cimg,H,W] (Cimg 3 or 4) with K = 9*Cimg;
  * w_oihw is the reference weight [Cout,Cimg,3,3] unpacked; out NHWC [B,H,W,Cout],
- * Cout a multiple of 4, <= 128. */
+ * Cout a multiple of 4, <= 128.  s2d_out: store space-to-depth
+ * [B,H/2,W/2,4*Cout] for a following 5x5/s2 layer run by Winograd. */
 int dsic_conv_first_nchw(const float* x_nchw, const float* w_oihw,
                          const float* bias, const float* beta,
                          const float* gamma, float* out_nhwc, int B, int Cimg,
-                         int H, int W, int Cout, int act, void* stream);
+                         int H, int W, int Cout, int act, int s2d_out,
+                         void* stream);
 
 /* ConvTranspose2d(Cin,Cout,5,2,2,output_padding=1) + optional IGDN/ReLU.
  * in NHWC [B,H,W,Cin] -> out NHWC [B,2H,2W,Cout]. */

@@ -225,3 +225,40 @@ def test_winograd_conv_vs_oracle(ops, B, Cin, Cout, H, W, act):
     ref64 = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
     if act == "none":
         assert float((got.double() - ref64).abs().max()) < 2e-5 * float(ref64.abs().max())
+
+
+@pytest.mark.parametrize("B,Cs,Cout,H,W,act", [(1, 128, 128, 32, 64, "gdn"), (2, 128, 128, 20, 36, "none"),
+                                               (1, 64, 64, 16, 16, "relu"), (3, 128, 128, 6, 10, "gdn")])
+def test_conv5x5_stride2_as_winograd_over_space_to_depth(ops, B, Cs, Cout, H, W, act):
+    """conv(C,C,5,2) == 3x3 Winograd over the space-to-depth input with 4*C channels."""
+    x = _rand((B, Cs, H, W), 51, 2.0)
+    w = _rand((Cout, Cs, 5, 5), 52, (Cs * 25) ** -0.5 * 2)
+    b = _rand((Cout,), 53, 0.5)
+    beta_p = torch.sqrt(0.5 + torch.rand(Cout, generator=torch.Generator().manual_seed(4)) + 2 ** -18)
+    gam_p = torch.sqrt(0.02 + 0.28 * torch.rand(Cout, generator=torch.Generator().manual_seed(5)) + 2 ** -18)
+    ref = O._conv({"p.weight": w, "p.bias": b}, "p", x, 2)
+    code = {"none": ops.ACT_NONE, "gdn": ops.ACT_GDN, "relu": ops.ACT_RELU}[act]
+    if act == "gdn":
+        ref = O.gdn(ref, beta_p, gam_p.view(-1, 1, 1, 1), False)
+    elif act == "relu":
+        ref = torch.relu(ref)
+    xs = ops.space_to_depth(_nhwc(x).cuda())
+    y = ops.conv3x3_wino_nhwc(xs, ops.pack_wino_s2_weight(w.cuda()), b.cuda(), Cout, code,
+                              (beta_p ** 2 - 2 ** -18).cuda(), (gam_p ** 2 - 2 ** -18).cuda())
+    got = ops.nhwc_to_nchw(y).cpu()
+    assert got.shape == ref.shape
+    err = float((got - ref).abs().max())
+    assert err <= _tol(ref, Cs * 25) * 6, (err, float(ref.abs().max()))
+
+
+def test_space_to_depth_epilogues(ops):
+    """The s2d_out stores of the first-layer and Winograd kernels equal space_to_depth(normal output)."""
+    x = _rand((2, 3, 16, 32), 61, 1.0).cuda()
+    w = _rand((128, 3, 3, 3), 62, 0.4).cuda()
+    b = _rand((128,), 63, 0.5).cuda()
+    a = ops.conv_first_nchw(x, w, b)
+    assert torch.equal(ops.conv_first_nchw(x, w, b, s2d_out=True), ops.space_to_depth(a))
+    assert torch.equal(ops.depth_to_space(ops.space_to_depth(a)), a)
+    w2 = ops.pack_wino_weight(_rand((128, 128, 3, 3), 64, 0.05).cuda())
+    y = ops.conv3x3_wino_nhwc(a, w2, b, 128)
+    assert torch.equal(ops.conv3x3_wino_nhwc(a, w2, b, 128, s2d_out=True), ops.space_to_depth(y))
