@@ -55,10 +55,12 @@ def _conv_kernel_name(win, stride, Wo, Cin, CoutP):
     return f"conv_igemm_kernel<{win},{stride},{tile[0]},{tile[1]},{tile[2]},{ck},{ntw},{narrow}>"
 
 
-def _timed(name, flops, launch):
+def _timed(name, flops, launch, exec_flops=None):
+    """flops: algorithmic (direct-convolution) FLOPs of the launch; exec_flops: FLOPs the MFMA
+    pipe actually executes (smaller for Winograd, larger where channels are padded)."""
     if _kernel_timer is None:
         return launch()
-    return _kernel_timer.record(name, flops, launch)
+    return _kernel_timer.record(name, flops, launch, exec_flops if exec_flops is not None else flops)
 
 
 def round_up(a: int, b: int) -> int:
@@ -188,10 +190,12 @@ def conv3x3_wino_nhwc(x, u_packed, bias, Cout, act=ACT_NONE, beta=None, gamma=No
         shape = (B, H // 2, W // 2, 4 * Cout) if s2d_out else (B, H, W, Cout)
         out = torch.empty(shape, dtype=torch.float32, device=x.device)
     L = _lib.load()
+    wino_tiles = B * (-(-H // 8)) * (-(-W // 16)) * 32          # 2x2-output tiles incl. border padding
     _timed("conv_wino_kernel", algo_flops if algo_flops is not None else 2.0 * B * H * W * Cout * Cin * 9,
            lambda: _lib.check(L.dsic_conv3x3_wino_nhwc(_p(x), _p(u_packed), _p(bias), _p(beta), _p(gamma), _p(out),
                                                        B, H, W, Cin, Cout, act, int(bool(s2d_out)), _stream()),
-                              "conv3x3_wino_nhwc"))
+                              "conv3x3_wino_nhwc"),
+           exec_flops=2.0 * wino_tiles * 16 * Cin * round_up(Cout, 32))
     return out
 
 
