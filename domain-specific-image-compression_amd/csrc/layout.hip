@@ -107,6 +107,19 @@ __global__ void transpose_kernel(const float* __restrict__ src, float* __restric
   }
 }
 
+// F.pad(x, (0,pad_w,0,pad_h), mode="reflect") of modelseval.py:57-64 (bottom/right only).
+__global__ void reflect_pad_br_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W,
+                                      int Hp, int Wp, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int x = i % Wp;
+  const int y = (i / Wp) % Hp;
+  const int64_t plane = i / ((int64_t)Wp * Hp);
+  const int sy = y < H ? y : 2 * (H - 1) - y;  // reflect without repeating the edge
+  const int sx = x < W ? x : 2 * (W - 1) - x;
+  dst[i] = src[(plane * H + sy) * W + sx];
+}
+
 static int transpose_launch(const float* src, float* dst, int B, int R, int Cc, hipStream_t st) {
   dim3 grid(ceil_div(Cc, 32), ceil_div(R, 32), B), block(32, 8);
   hipLaunchKernelGGL(transpose_kernel, grid, block, 0, st, src, dst, R, Cc);
@@ -174,4 +187,15 @@ extern "C" int dsic_nchw_to_nhwc(const float* src, float* dst, int B, int C, int
                                  void* stream) {
   DSIC_REQUIRE(src && dst && B > 0 && H > 0 && W > 0 && C > 0, "nchw_to_nhwc: bad argument");
   return transpose_launch(src, dst, B, C, H * W, (hipStream_t)stream);
+}
+
+extern "C" int dsic_reflect_pad_br(const float* src, float* dst, int planes, int H, int W, int pad_h,
+                                   int pad_w, void* stream) {
+  DSIC_REQUIRE(src && dst && planes > 0 && H > 0 && W > 0 && pad_h >= 0 && pad_w >= 0, "reflect_pad: bad argument");
+  DSIC_REQUIRE(pad_h < H && pad_w < W, "reflect_pad: padding (%d,%d) must be smaller than the image (%d,%d)", pad_h, pad_w, H, W);
+  const int Hp = H + pad_h, Wp = W + pad_w;
+  const int64_t total = (int64_t)planes * Hp * Wp;
+  hipLaunchKernelGGL(reflect_pad_br_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, src, dst, H, W, Hp, Wp, total);
+  return check_launch("reflect_pad");
 }

@@ -18,6 +18,21 @@ from .ops import _f32c, _p, _stream
 DEFAULT_WEIGHTS = (0.0448, 0.2856, 0.3001, 0.2363, 0.1333)
 
 
+def pad_to_multiple_tensor(x, multiple=16):
+    """modelseval.py:57-64: reflect-pad bottom/right so H and W are multiples of `multiple`.
+    Returns (x_padded, pad_h, pad_w)."""
+    x = _f32c(x, "pad_to_multiple_tensor")
+    B, C, h, w = x.shape
+    pad_h = (multiple - h % multiple) % multiple
+    pad_w = (multiple - w % multiple) % multiple
+    if pad_h == 0 and pad_w == 0:
+        return x, 0, 0
+    out = torch.empty((B, C, h + pad_h, w + pad_w), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().dsic_reflect_pad_br(_p(x), _p(out), B * C, h, w, pad_h, pad_w, _stream()),
+               "reflect_pad_br")
+    return out, pad_h, pad_w
+
+
 def _levels(X, Y, n_levels, data_range, clamp_x):
     """-> means [levels, B*C, 2] (mean cs, mean ssim) as a device fp64 tensor."""
     X = _f32c(X, "ms_ssim")

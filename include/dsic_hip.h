@@ -73,6 +73,11 @@ int dsic_nhwc_to_nchw(const float* src, float* dst, int B, int H, int W, int C,
 int dsic_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W,
                       void* stream);
 
+/* F.pad(x,(0,pad_w,0,pad_h),mode="reflect") on [planes,H,W] (modelseval.py:57-64:
+ * pad bottom/right to a multiple of 16).  dst: [planes,H+pad_h,W+pad_w]. */
+int dsic_reflect_pad_br(const float* src, float* dst, int planes, int H, int W,
+                        int pad_h, int pad_w, void* stream);
+
 /* ---- convolutions (fp32 MFMA implicit GEMM, fused bias + activation) ----- */
 
 /* conv() + optional GDN/ReLU: nn.Conv2d(Cin,Cout,k,stride,padding=(k-1)/2)

@@ -79,3 +79,43 @@ def test_rate_distortion_loss_matches_oracle():
     assert abs(D2.item() - want) < 1e-4
     with pytest.raises(ValueError):
         rate_distortion_loss(out, x.cuda(), 1.0, "psnr")
+
+
+def test_reflect_pad_and_evaluate_batch_like_modelseval():
+    """120x120 patches (the reference's BigEarthNet size): pad to 128, crop back, SSIM fallback."""
+    from dsic_amd import evaluate, metrics
+    from dsic_amd.model import CompressionModel
+    from oracle import ref_model as O
+    x = torch.from_numpy(S.make_patches(70, 2, 120, 120))
+    xp, ph, pw = metrics.pad_to_multiple_tensor(x.cuda(), 16)
+    want, wh, ww = RM.pad_to_multiple_tensor(x, 16)
+    assert (ph, pw) == (wh, ww) == (8, 8) and torch.equal(xp.cpu(), want)
+    same, a, b = metrics.pad_to_multiple_tensor(xp, 16)
+    assert (a, b) == (0, 0) and same.data_ptr() == xp.data_ptr()
+    sd = S.make_state_dict(seed=1)
+    m = CompressionModel(min_nu=2).cuda().eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    rows = evaluate.evaluate_batch(m, x.cuda())
+    ref = O.forward(sd, want, "round")
+    for i in range(2):
+        xh = ref["x_hat"][i:i + 1, :, :120, :120].clamp(0, 1)
+        bpp = float((ref["nll_y"][i].double().sum() + ref["nll_z"][i].double().sum()) / (120 * 120))
+        assert abs(rows[i]["bpp"] - bpp) < 1e-4
+        assert abs(rows[i]["mse"] - RM.compute_mse(xh, x[i:i + 1])) < 1e-6
+        assert abs(rows[i]["psnr"] - RM.compute_psnr(xh, x[i:i + 1])) < 1e-3
+        assert abs(rows[i]["msssim"] - RM.ssim(xh, x[i:i + 1], data_range=1.0).item()) < 1e-4
+
+
+def test_evaluate_image_like_the_entropy_script():
+    from dsic_amd import evaluate
+    from dsic_amd.model import CompressionModel
+    sd = S.make_state_dict(seed=1)
+    m = CompressionModel(min_nu=2).cuda().eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    x = torch.from_numpy(S.make_patches(80, 1, 176, 176)).cuda()
+    r = evaluate.evaluate_image(m, x)
+    assert 0.97 * r["bpp_est"] < r["bpp_real"] < 1.10 * r["bpp_est"]
+    out = m(x, "round")
+    assert torch.equal(r["x_hat"], out["x_hat"].clamp(0, 1))
+    want = RM.ms_ssim(r["x_hat"].cpu(), x.cpu(), data_range=1.0).item()
+    assert abs(r["ms_ssim5"] - want) < 1e-4
