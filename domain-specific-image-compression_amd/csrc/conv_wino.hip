@@ -21,6 +21,8 @@
 // position halves exchange partial inverse transforms through LDS, each wave
 // finishes one output row parity, applies bias + activation and stores 16 bytes
 // per lane through the LDS transpose.
+#include <stdlib.h>
+
 #include "common.h"
 
 #ifndef WINO_STAMP
@@ -416,7 +418,15 @@ extern "C" int dsic_conv3x3_wino_nhwc(const float* in, const float* u_packed, co
     }
     attr_set = true;
   }
-  const int grid = a.ntiles < 256 ? a.ntiles : 256;  // persistent: one workgroup per CU
+  // persistent: one workgroup per CU.  DSIC_WINO_GRID lowers the count when the launching stream
+  // owns fewer CUs (CU-masked streams, dsic_stream_create_masked).
+  static int max_grid = 0;
+  if (max_grid == 0) {
+    const char* g = getenv("DSIC_WINO_GRID");
+    max_grid = g ? atoi(g) : 256;
+    if (max_grid < 1 || max_grid > 1024) max_grid = 256;
+  }
+  const int grid = a.ntiles < max_grid ? a.ntiles : max_grid;
   hipLaunchKernelGGL(conv_wino_kernel, dim3(grid), dim3(512), WLDS_BYTES, (hipStream_t)stream, a);
   return check_launch("conv3x3_wino");
 }

@@ -88,13 +88,47 @@ __global__ __launch_bounds__(256) void tables_kernel(const float* __restrict__ s
   if (lane == 0) dm::finish_table(F, L, tables + ((size_t)b * C + c) * Lmax, work);
 }
 
-// Range encoder, one wave per (image, stream): stream id = b*2 + which (0: z
-// string, 1: y string); four streams (one per SIMD) share a workgroup so that a
-// batch occupies few CUs and leaves the rest to concurrently running conv kernels.  Each lane translates one symbol of a 64-symbol group to
-// its (c_low, c_high-1) pair (table gather, prefetched one group ahead); the
-// interval recurrence then runs on wave-uniform values - read lane by lane with
-// v_readlane - so it executes on the scalar unit; only the 32-bit flushes of
-// the bit accumulator touch memory (lane 0).
+// Range encoder, one wave per (image, stream): stream id = b*2 + which (0: z string,
+// 1: y string); several streams (one per SIMD) share a workgroup.
+//
+// The coder is split along its only true dependency.  (1) The interval recurrence
+// (low, high, pending) is a serial chain per stream: it runs branch-free on wave-uniform
+// values (scalar unit), reading the (c_low, c_high-1) pair of symbol j with v_readlane from a
+// register the 64 lanes filled in parallel (table gather, pipelined two groups ahead), and
+// records per symbol only WHAT is emitted: the nb leading bits of low that became final and
+// the pending count flushed behind the first of them (v_writelane).  (2) WHERE those bits go
+// is a prefix sum: every 64 symbols the lanes scan their bit counts and OR their pieces into
+// the zero-initialised output with atomics, in parallel.  Bytes are identical to the
+// bit-serial reference loop (torchac): E1/E2 shifts = clz(low^high) at once, E3 run = leading
+// ones of (low<<1)&~(high<<1).
+__device__ __forceinline__ void put_bits(uint32_t* out32, int64_t cap_bits, int64_t off, uint32_t v,
+                                         int len, int* overflow) {
+  // append the low `len` (1..32) bits of v at bit offset `off`, MSB first
+  if (off + len > cap_bits) {
+    *overflow = 1;
+    return;
+  }
+  const int64_t w = off >> 5;
+  const int s = (int)(off & 31), space = 32 - s;
+  if (len <= space) {
+    atomicOr(out32 + w, __builtin_bswap32(v << (space - len)));
+  } else {
+    const int rest = len - space;
+    atomicOr(out32 + w, __builtin_bswap32(v >> rest));
+    atomicOr(out32 + w + 1, __builtin_bswap32(v << (32 - rest)));
+  }
+}
+
+__device__ __forceinline__ void put_ones(uint32_t* out32, int64_t cap_bits, int64_t off, uint32_t count,
+                                         int* overflow) {
+  while (count > 0) {
+    const int len = count > 32 ? 32 : (int)count;
+    put_bits(out32, cap_bits, off, len == 32 ? 0xFFFFFFFFu : ((1u << len) - 1u), len, overflow);
+    off += len;
+    count -= len;
+  }
+}
+
 __global__ __launch_bounds__(1024) void range_encode_kernel(
     const float* __restrict__ y, const float* __restrict__ z, const int* __restrict__ meta,
     const uint16_t* __restrict__ tab_y, const uint16_t* __restrict__ tab_z, int Lmax, int M, int HWy,
@@ -109,10 +143,9 @@ __global__ __launch_bounds__(1024) void range_encode_kernel(
   const float* sym = which ? y + (size_t)b * n : z + (size_t)b * n;
   const uint16_t* tab = (which ? tab_y + (size_t)b * M * Lmax : tab_z + (size_t)b * N * Lmax);
   const int smin = meta[4 * b + (which ? 0 : 2)], L = meta[4 * b + (which ? 1 : 3)];
-  const int64_t stride = cap_z + cap_y;  // per image: [z bytes | y bytes]
-  uint8_t* dst = out + (size_t)b * stride + (which ? cap_z : 0);
-  uint32_t* dst32 = (uint32_t*)dst;
-  const int64_t cap = which ? cap_y : cap_z;
+  const int64_t stride = cap_z + cap_y;  // per image: [z bytes | y bytes], zero-initialised by the caller
+  uint32_t* dst32 = (uint32_t*)(out + (size_t)b * stride + (which ? cap_z : 0));
+  const int64_t cap_bits = (which ? cap_y : cap_z) * 8;
   if (L > Lmax || L < 1) {
     if (lane == 0) {
       atomicOr(err, 1);
@@ -121,10 +154,9 @@ __global__ __launch_bounds__(1024) void range_encode_kernel(
     return;
   }
 
-  // Two-deep software pipeline for the operand gather: symbols are loaded two
-  // groups ahead, their table entries one group ahead, so neither dependent
-  // load round sits on the serial chain even when L2 latency is several
-  // microseconds under a co-running conv kernel.
+  // Two-deep software pipeline for the operand gather: symbols are loaded two groups ahead,
+  // their table entries one group ahead, so neither dependent load round sits on the serial
+  // chain even when L2 latency is several microseconds under a co-running conv kernel.
   auto sym_of = [&](int64_t g) -> float { return g < n ? sym[g] : 0.f; };
   auto pair_of = [&](float v, int64_t g) -> uint32_t {
     if (g >= n) return 0u;
@@ -141,32 +173,8 @@ __global__ __launch_bounds__(1024) void range_encode_kernel(
   };
 
   uint32_t low = 0, high = 0xFFFFFFFFu, pending = 0;
-  uint64_t acc = 0;   // bit accumulator, newest bit at the bottom
-  int nbits = 0;      // valid bits in acc (< 32 between symbols)
-  int64_t nbytes = 0;
+  int64_t base_bits = 0;  // bits emitted so far (wave-uniform)
   int overflow = 0;
-
-  auto put = [&](uint32_t v, int len) {  // append the low `len` (1..32) bits of v
-    acc = (acc << len) | (uint64_t)v;
-    nbits += len;
-    if (nbits >= 32) {
-      const uint32_t w = (uint32_t)(acc >> (nbits - 32));
-      if (nbytes + 4 <= cap) {
-        dst32[nbytes >> 2] = __builtin_bswap32(w);  // every lane stores the same dword: keeps the state scalar
-      } else {
-        overflow = 1;
-      }
-      nbytes += 4;
-      nbits -= 32;
-    }
-  };
-  auto put_run = [&](uint32_t bit, uint32_t count) {
-    while (count > 0) {
-      const int len = count > 32 ? 32 : (int)count;
-      put(bit ? (len == 32 ? 0xFFFFFFFFu : ((1u << len) - 1u)) : 0u, len);
-      count -= len;
-    }
-  };
 
   uint32_t cur = pair_of(sym_of(lane), lane);
   float sym1 = sym_of(64 + lane);
@@ -174,6 +182,7 @@ __global__ __launch_bounds__(1024) void range_encode_kernel(
     const float sym2 = sym_of(base + 128 + lane);
     const uint32_t nxt = pair_of(sym1, base + 64 + lane);
     const int cnt = (int)((n - base) < 64 ? (n - base) : 64);
+    uint32_t rec0 = 0, rec1 = 0;  // lane j: (nb << 24 | bits) and the pending count flushed at symbol j
     for (int j = 0; j < cnt; ++j) {
       const uint32_t pr = __builtin_amdgcn_readlane(cur, j);
       const uint32_t c_low = pr & 0xFFFFu, c_high = (pr >> 16) + 1u;
@@ -183,56 +192,70 @@ __global__ __launch_bounds__(1024) void range_encode_kernel(
       const uint32_t lo_add = (uint32_t)(((uint64_t)r * c_low + c_low) >> 16);
       high = (low - 1u) + hi_add;
       low = low + lo_add;
-      // Between symbols high - low >= 2^30 (MSBs differ, no E3 pending), every
-      // table interval is >= 1/65536, so the new interval is >= 2^14 - 2 wide:
-      // low != high and at most 18 leading bits agree.
-      // E1/E2: nb leading bits agree -> emit them (pending inverse bits after the first)
-      const int nb = __builtin_clz(low ^ high);
-      if (nb > 0) {
-        if (pending == 0) {
-          put(low >> (32 - nb), nb);
-        } else {
-          const uint32_t first = low >> 31;
-          put(first, 1);
-          put_run(first ^ 1u, pending);
-          pending = 0;
-          if (nb > 1) put((low << 1) >> (33 - nb), nb - 1);
-        }
-        low <<= nb;
-        high = (high << nb) | ((1u << nb) - 1u);
-      }
-      // E3: low = 01.., high = 10..: m consecutive (1,0) pairs below the MSB
-      const uint32_t e3 = (low << 1) & ~(high << 1);  // bit 0 is 0, so ~e3 != 0
+      // Between symbols high - low >= 2^30 (MSBs differ, no E3 pending) and every table interval
+      // is >= 1/65536, so the new interval is >= 2^14 - 2 wide: low != high, nb <= 18.
+      const int nb = __builtin_clz(low ^ high);             // E1/E2: leading bits now final
+      const uint32_t bits = (low >> 1) >> (31 - nb);        // those nb bits (0 when nb == 0)
+      const uint32_t flush = nb ? pending : 0u;             // inverse bits owed behind the first one
+      pending = nb ? 0u : pending;
+      // v_writelane has no clang builtin on this toolchain.  The lane select goes through M0
+      // (an SGPR value plus an SGPR lane select would exceed the constant-bus limit); s_nop 3:
+      // an SALU result needs 4 wait states before it is used as a lane select, and hipcc pads
+      // nothing inside asm.  The kernel uses no LDS, GWS or movrel, so M0 is otherwise unused.
+      const uint32_t w0 = bits | ((uint32_t)nb << 24);
+      asm volatile("s_mov_b32 m0, %4\n\ts_nop 3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+                   : "+v"(rec0), "+v"(rec1)
+                   : "s"(w0), "s"(flush), "s"(j));
+      low <<= nb;
+      high = (high << nb) | ((1u << nb) - 1u);
+      // E3: low = 01.., high = 10..: m consecutive (1,0) bit pairs below the MSB
+      const uint32_t e3 = (low << 1) & ~(high << 1);        // bit 0 is 0, so ~e3 != 0
       const int m = __builtin_clz(~e3);
-      if (m > 0) {
-        pending += (uint32_t)m;
-        low = (low << m) & 0x7FFFFFFFu;
-        high = (high << m) | 0x80000000u | ((1u << m) - 1u);
+      pending += (uint32_t)m;
+      low = (low << m) & 0x7FFFFFFFu;                       // MSB(low) is 0 here, so m == 0 is a no-op
+      high = (high << m) | 0x80000000u | ((1u << m) - 1u);
+    }
+    // parallel placement of this group's bits
+    {
+      const uint32_t nbv = rec0 >> 24, bitsv = rec0 & 0xFFFFFFu, pendv = rec1;
+      const uint32_t len = nbv + pendv;
+      uint32_t incl = len;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
       }
+      const int64_t off = base_bits + (int64_t)(incl - len);
+      if (nbv > 0) {
+        if (pendv == 0) {
+          put_bits(dst32, cap_bits, off, bitsv, (int)nbv, &overflow);
+        } else {
+          const uint32_t first = bitsv >> (nbv - 1);
+          put_bits(dst32, cap_bits, off, first, 1, &overflow);
+          if (!first) put_ones(dst32, cap_bits, off + 1, pendv, &overflow);   // inverse bits are 1s
+          else if (off + 1 + (int64_t)pendv > cap_bits) overflow = 1;
+          if (nbv > 1)
+            put_bits(dst32, cap_bits, off + 1 + pendv, bitsv & ((1u << (nbv - 1)) - 1u), (int)nbv - 1, &overflow);
+        }
+      }
+      base_bits += (int64_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
     cur = nxt;
     sym1 = sym2;
   }
-  // flush (torchac): one more pending bit, then the deciding bit and the pending run
+  // flush (torchac): one more pending bit, then the deciding bit and the pending run, zero padded
   pending += 1;
   const uint32_t bit = low < 0x40000000u ? 0u : 1u;
-  put(bit, 1);
-  put_run(bit ^ 1u, pending);
-  while (nbits > 0) {  // tail bytes, zero padded
-    const int take = nbits >= 8 ? 8 : nbits;
-    const uint32_t v = (uint32_t)((acc >> (nbits - take)) & ((1u << take) - 1u)) << (8 - take);
-    if (nbytes < cap) {
-      dst[nbytes] = (uint8_t)v;
-    } else {
-      overflow = 1;
-    }
-    nbytes += 1;
-    nbits -= take;
-  }
   if (lane == 0) {
-    lengths[2 * b + which] = (int)nbytes;
-    if (overflow) atomicOr(err, 4);
+    put_bits(dst32, cap_bits, base_bits, bit, 1, &overflow);
+    if (!bit) put_ones(dst32, cap_bits, base_bits + 1, pending, &overflow);
+    else if (base_bits + 1 + (int64_t)pending > cap_bits) overflow = 1;
   }
+  const int64_t total_bits = base_bits + 1 + (int64_t)pending;
+  if (__any(overflow)) {
+    if (lane == 0) atomicOr(err, 4);
+  }
+  if (lane == 0) lengths[2 * b + which] = (int)((total_bits + 7) >> 3);
 }
 
 struct BitSource {

@@ -92,7 +92,7 @@ def compress_latents(y_tilde, z_tilde, sigma_y, nu_y, sigma_z, tail=10, Lmax=DEF
     meta = latent_support(y, z, tail)
     tab_y, tab_z, err = cdf_tables(sigma_y, nu_y, sigma_z, meta, Lmax)
     cap_y, cap_z = _cap(M * Hy * Wy), _cap(N * Hz * Wz)
-    out = torch.empty((B, cap_z + cap_y), dtype=torch.uint8, device=dev)
+    out = torch.zeros((B, cap_z + cap_y), dtype=torch.uint8, device=dev)   # the coder ORs its bits in
     lengths = torch.zeros((B, 2), dtype=torch.int32, device=dev)
     _lib.check(_lib.load().dsic_range_encode(_p(y), _p(z), _p(meta), _p(tab_y), _p(tab_z), Lmax, B, M, Hy * Wy,
                                              N, Hz * Wz, _p(out), cap_y, cap_z, _p(lengths), _p(err),
@@ -101,13 +101,20 @@ def compress_latents(y_tilde, z_tilde, sigma_y, nu_y, sigma_z, tail=10, Lmax=DEF
             "tab_y": tab_y, "tab_z": tab_z, "err": err, "shape_y": list(y.shape), "shape_z": list(z.shape)}
 
 
-def masked_streams(coder_cus, total_cus=256):
-    """(main, coder) torch ExternalStreams: the coder owns the LAST `coder_cus`
-    CUs of the mask order, everything else runs on the remaining ones."""
+def masked_streams(coder_cus=16, total_cus=256, xcds=8):
+    """(main, coder) torch ExternalStreams on disjoint CU sets.
+
+    The coder gets coder_cus/xcds CUs of EVERY XCD (workgroups are dealt round-robin over the
+    XCDs, so removing CUs from one XCD only would make it the straggler of every conv launch).
+    The pattern k*32+j with j = k, k+8, ... selects the same number of CUs per XCD whether mask
+    bits enumerate CUs XCD-major or XCD-interleaved."""
     L = _lib.load()
     words = (total_cus + 31) // 32
+    per_xcd = max(1, coder_cus // xcds)
     bits = np.zeros(total_cus, dtype=bool)
-    bits[total_cus - coder_cus:] = True
+    for k in range(xcds):
+        for t in range(per_xcd):
+            bits[k * (total_cus // xcds) + (k + 8 * t) % (total_cus // xcds)] = True
 
     def make(sel):
         m = np.zeros(words, dtype=np.uint32)

@@ -231,7 +231,8 @@ int dsic_cdf_tables_student(const float* sigma, const float* nu,
                             int Lmax, int* err, void* stream);
 
 /* torchac.encode_float_cdf call sites :48,62: per image the z string then the
- * y string.  out: [B][cap_z + cap_y] bytes (z at offset 0, y at cap_z),
+ * y string.  out: [B][cap_z + cap_y] bytes, ZERO-INITIALISED by the caller (bits
+ * are OR-ed in; z at offset 0, y at cap_z),
  * lengths [B][2] = {len_z, len_y}.  Symbol order C,H,W of the NCHW latents. */
 int dsic_range_encode(const float* y_nchw, const float* z_nchw, const int* meta,
                       const uint16_t* tab_y, const uint16_t* tab_z, int Lmax,
