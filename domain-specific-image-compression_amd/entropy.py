@@ -251,3 +251,48 @@ def real_bpp(compressed, H, W):
     """:148-149 — 8 * total bytes / (H*W), per batch."""
     total_bits = sum(len(s) * 8 for entry in compressed["strings"] for s in entry)
     return total_bits / float(H * W)
+
+
+# ---- container: the reference keeps the compressed patch batch as an in-memory dict (:68-74);
+# this is that dict as one byte string, so the strings can leave the process ------------------
+_MAGIC = b"DSIC1\x00"
+
+
+def pack_container(compressed) -> bytes:
+    """dict of custom_compress -> bytes.  Layout (little endian):
+    magic(6) | B,My,Hy,Wy,Nz,Hz,Wz (7 x uint32) | per image: min_y,max_y,min_z,max_z (4 x int32),
+    len_z,len_y (2 x uint32) | per image: z bytes, y bytes."""
+    import struct
+    B, My, Hy, Wy = compressed["shape_y"]
+    _, Nz, Hz, Wz = compressed["shape_z"]
+    head = [_MAGIC, struct.pack("<7I", B, My, Hy, Wy, Nz, Hz, Wz)]
+    body = []
+    for b in range(B):
+        zs, ys = compressed["strings"][b]
+        head.append(struct.pack("<4i2I", compressed["min_y"][b], compressed["max_y"][b], compressed["min_z"][b],
+                                compressed["max_z"][b], len(zs), len(ys)))
+        body += [zs, ys]
+    return b"".join(head + body)
+
+
+def unpack_container(blob: bytes):
+    """Inverse of pack_container."""
+    import struct
+    if blob[:6] != _MAGIC:
+        raise ValueError("not a DSIC container")
+    B, My, Hy, Wy, Nz, Hz, Wz = struct.unpack_from("<7I", blob, 6)
+    off = 6 + 28
+    meta = [struct.unpack_from("<4i2I", blob, off + 24 * b) for b in range(B)]
+    off += 24 * B
+    strings = []
+    for m in meta:
+        zs = blob[off:off + m[4]]
+        off += m[4]
+        ys = blob[off:off + m[5]]
+        off += m[5]
+        strings.append([zs, ys])
+    if off != len(blob):
+        raise ValueError("truncated or oversized DSIC container")
+    return {"strings": strings, "shape_y": [B, My, Hy, Wy], "shape_z": [B, Nz, Hz, Wz],
+            "min_y": [m[0] for m in meta], "max_y": [m[1] for m in meta],
+            "min_z": [m[2] for m in meta], "max_z": [m[3] for m in meta]}

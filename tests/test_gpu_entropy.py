@@ -118,3 +118,18 @@ def test_errors_are_reported(model):
                                  torch.ones(2, device="cuda"), tail=10, Lmax=64)
     with pytest.raises(entropy.EntropyError):
         entropy._check_err(c["err"], "test")
+
+
+def test_container_round_trip(model):
+    from dsic_amd import entropy
+    x = torch.from_numpy(S.make_patches(400, 2, 64, 80)).cuda()
+    c = entropy.custom_compress(model, x)
+    blob = entropy.pack_container(c)
+    back = entropy.unpack_container(blob)
+    assert back == c
+    assert len(blob) == 6 + 28 + 24 * 2 + sum(len(s) for e in c["strings"] for s in e)
+    assert torch.equal(entropy.custom_decompress(model, back), model(x, "round")["x_hat"].clamp(0, 1))
+    with pytest.raises(ValueError):
+        entropy.unpack_container(blob[:-1])
+    with pytest.raises(ValueError):
+        entropy.unpack_container(b"nope" + blob)
