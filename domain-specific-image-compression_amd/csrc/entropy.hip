@@ -258,83 +258,129 @@ __global__ __launch_bounds__(1024) void range_encode_kernel(
   if (lane == 0) lengths[2 * b + which] = (int)((total_bits + 7) >> 3);
 }
 
-struct BitSource {
-  const uint8_t* in;
-  int64_t n, pos;
-  int bit;
-  __device__ __forceinline__ uint32_t get() {
-    if (pos >= n) return 0;
-    const uint32_t v = (in[pos] >> (7 - bit)) & 1u;
-    if (++bit == 8) {
-      bit = 0;
-      ++pos;
-    }
-    return v;
-  }
-};
-
-// One stream per block; lane 0 decodes.  in: [B] strings at stride `stride` bytes,
-// lengths[b*lstride + loff]; out: NCHW float latents (symbol + smin).
-__global__ __launch_bounds__(64) void range_decode_kernel(const uint8_t* __restrict__ in,
-                                                          int64_t stride,
-                                                          const int* __restrict__ lengths, int lstride,
-                                                          int loff, const int* __restrict__ meta,
-                                                          int meta_off,
-                                                          const uint16_t* __restrict__ tables, int Lmax,
-                                                          int C, int HW, float* __restrict__ out,
-                                                          int* __restrict__ err) {
-  extern __shared__ uint16_t stab[];  // this image's tables [C][L] when they fit
-  const int b = blockIdx.x;
+// Range decoder, one wave per stream (torchac decode_float_cdf, call sites :96,116).
+//
+// The reference computes count = ((value-low+1)*2^16 - 1) / span and searches the table for
+// c[s] <= count < c[s+1].  For integers that is exactly  floor(span*c[s] / 2^16) <= value-low
+// (no division), and the predicate is monotone in s, so all 64 lanes test one table entry each
+// and a ballot + popcount gives s.  The interval update and renormalisation mirror the
+// encoder (bulk shifts by clz); `value` takes the same shifts with fresh stream bits, and the
+// m-step E3 correction  v <- 2(v - 2^30) + bit  collapses to flipping the top bit.  Stream
+// bytes are fetched 256 at a time by the wave (zero past the end, like torchac's reader).
+__global__ __launch_bounds__(256) void range_decode_kernel(const uint8_t* __restrict__ in,
+                                                           int64_t stride,
+                                                           const int* __restrict__ lengths, int lstride,
+                                                           int loff, const int* __restrict__ meta,
+                                                           int meta_off,
+                                                           const uint16_t* __restrict__ tables, int Lmax,
+                                                           int C, int HW, float* __restrict__ out,
+                                                           int* __restrict__ err, int B) {
+  const int lane = threadIdx.x & 63;
+  const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  if (b >= B) return;
   const int smin = meta[4 * b + meta_off], L = meta[4 * b + meta_off + 1];
   if (L > Lmax || L < 1) {
-    if (threadIdx.x == 0) atomicOr(err, 1);
+    if (lane == 0) atomicOr(err, 1);
     return;
   }
   const uint16_t* gt = tables + (size_t)b * C * Lmax;
-  const bool in_lds = (size_t)C * L * 2 <= 48 * 1024;
-  if (in_lds) {
-    for (int i = threadIdx.x; i < C * L; i += 64) stab[i] = gt[(size_t)(i / L) * Lmax + (i % L)];
-  }
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  BitSource src{in + (size_t)b * stride, (int64_t)lengths[b * lstride + loff], 0, 0};
+  const uint32_t* src32 = (const uint32_t*)(in + (size_t)b * stride);  // stride is a multiple of 4
+  const int nbytes = lengths[b * lstride + loff];
+  const int ndw = (nbytes + 3) >> 2;
   const int64_t n = (int64_t)C * HW;
   float* dst = out + (size_t)b * n;
-  uint32_t low = 0, high = 0xFFFFFFFFu, value = 0;
-  for (int i = 0; i < 32; ++i) value = (value << 1) | src.get();
-  for (int64_t i = 0; i < n; ++i) {
-    const int c = (int)(i / HW);
-    const uint16_t* t = in_lds ? stab + (size_t)c * L : gt + (size_t)c * Lmax;
-    const uint64_t span = (uint64_t)high - (uint64_t)low + 1u;
-    const uint32_t count = (uint32_t)(((((uint64_t)value - (uint64_t)low + 1u) << 16) - 1u) / span);
-    int lo = 0, hi = L - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if ((uint32_t)t[mid] <= count)
-        lo = mid;
-      else
-        hi = mid - 1;
+
+  // 64-dword window of the stream, big-endian words, bytes >= nbytes read as zero
+  auto load_window = [&](int w0) -> uint32_t {
+    const int k = w0 + lane;
+    uint32_t v = 0;
+    if (k < ndw) {
+      v = __builtin_bswap32(src32[k]);
+      const int valid = nbytes - 4 * k;  // 1..4 valid bytes in the last dword
+      if (valid < 4) v &= 0xFFFFFFFFu << (8 * (4 - valid));
     }
-    const int s = lo;
-    dst[i] = (float)(s + smin);
-    if (i == n - 1) break;
-    const uint64_t c_low = t[s];
-    const uint64_t c_high = (s == L - 1) ? 0x10000u : (uint64_t)t[s + 1];
-    high = (low - 1u) + (uint32_t)((span * c_high) >> 16);
-    low = low + (uint32_t)((span * c_low) >> 16);
-    for (;;) {
-      if (low >= 0x80000000u || high < 0x80000000u) {
-        low <<= 1;
-        high = (high << 1) | 1u;
-        value = (value << 1) | src.get();
-      } else if (low >= 0x40000000u && high < 0xC0000000u) {
-        low = (low << 1) & 0x7FFFFFFFu;
-        high = (high << 1) | 0x80000001u;
-        value -= 0x40000000u;
-        value = (value << 1) | src.get();
-      } else {
-        break;
+    return v;
+  };
+  uint32_t win = load_window(0), win_next = load_window(64);
+  int wi = 0;  // next dword to feed into the bit buffer
+  auto next_dword = [&]() -> uint32_t {
+    const uint32_t d = __builtin_amdgcn_readlane(win, wi & 63);
+    ++wi;
+    if ((wi & 63) == 0) {
+      win = win_next;
+      win_next = load_window(wi + 64);
+    }
+    return d;
+  };
+  uint64_t bitbuf = ((uint64_t)next_dword() << 32);
+  bitbuf |= (uint64_t)next_dword();
+  int avail = 64;
+  auto take = [&](int k) -> uint32_t {  // next k (0..31) bits of the stream
+    const uint32_t v = k ? (uint32_t)(bitbuf >> (64 - k)) : 0u;
+    bitbuf <<= k;
+    avail -= k;
+    if (avail <= 32) {
+      bitbuf |= (uint64_t)next_dword() << (32 - avail);
+      avail += 32;
+    }
+    return v;
+  };
+
+  uint32_t low = 0, high = 0xFFFFFFFFu;
+  uint32_t value = take(16);
+  value = (value << 16) | take(16);
+
+  const int nseg = (L + 63) >> 6;  // table entries per channel, 64 per register
+  for (int c = 0; c < C; ++c) {
+    const uint16_t* t = gt + (size_t)c * Lmax;
+    for (int i = 0; i < HW; ++i) {
+      const uint32_t d = value - low;
+      const uint32_t r = high - low;  // span - 1
+      // s = (number of k in [0,L) with floor(span*c[k]/2^16) <= d) - 1
+      int cnt = 0;
+      uint32_t c_low = 0, c_high = 0x10000u, carry_low = 0;
+      bool carry = false;  // the previous 64-entry segment was entirely <= count
+      for (int seg = 0; seg < nseg; ++seg) {
+        const int k = seg * 64 + lane;
+        const uint32_t ck = k < L ? (uint32_t)t[k] : 0x10000u;  // entries past L act as c[L] = 65536
+        const uint32_t bound = (uint32_t)(((uint64_t)r * ck + ck) >> 16);
+        const int hits = __popcll(__ballot(k < L && bound <= d));
+        if (hits == 0) {  // only after a full segment (c[0] = 0 always hits)
+          if (carry) {
+            c_low = carry_low;
+            c_high = __builtin_amdgcn_readlane(ck, 0);
+          }
+          break;
+        }
+        cnt += hits;
+        if (hits < 64) {
+          c_low = __builtin_amdgcn_readlane(ck, hits - 1);
+          c_high = __builtin_amdgcn_readlane(ck, hits);
+          break;
+        }
+        carry = true;
+        carry_low = __builtin_amdgcn_readlane(ck, 63);
+        if (seg + 1 == nseg) {
+          c_low = carry_low;
+          c_high = 0x10000u;
+        }
       }
+      const int sidx = cnt - 1;
+      if (lane == 0) dst[(size_t)c * HW + i] = (float)(sidx + smin);
+      // interval update + renormalisation (same arithmetic as the encoder)
+      const uint32_t hi_add = (uint32_t)(((uint64_t)r * c_high + c_high) >> 16);
+      const uint32_t lo_add = (uint32_t)(((uint64_t)r * c_low + c_low) >> 16);
+      high = (low - 1u) + hi_add;
+      low = low + lo_add;
+      const int nb = __builtin_clz(low ^ high);
+      low <<= nb;
+      high = (high << nb) | ((1u << nb) - 1u);
+      value = nb ? ((value << nb) | take(nb)) : value;
+      const uint32_t e3 = (low << 1) & ~(high << 1);
+      const int m = __builtin_clz(~e3);
+      low = (low << m) & 0x7FFFFFFFu;
+      high = (high << m) | 0x80000000u | ((1u << m) - 1u);
+      value = m ? (((value << m) | take(m)) ^ 0x80000000u) : value;
     }
   }
 }
@@ -404,8 +450,9 @@ extern "C" int dsic_range_decode(const uint8_t* in, int64_t stride, const int* l
   DSIC_REQUIRE(in && lengths && meta && tables && out_nchw && err, "range_decode: null pointer");
   DSIC_REQUIRE(B > 0 && C > 0 && HW > 0 && Lmax >= 1, "range_decode: bad argument");
   DSIC_REQUIRE(meta_off == 0 || meta_off == 2, "range_decode: meta_off must be 0 (y) or 2 (z)");
-  hipLaunchKernelGGL(range_decode_kernel, dim3(B), dim3(64), 48 * 1024, (hipStream_t)stream, in, stride,
-                     lengths, lstride, loff, meta, meta_off, tables, Lmax, C, HW, out_nchw, err);
+  DSIC_REQUIRE(stride % 4 == 0, "range_decode: stride must be a multiple of 4");
+  hipLaunchKernelGGL(range_decode_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, (hipStream_t)stream, in, stride,
+                     lengths, lstride, loff, meta, meta_off, tables, Lmax, C, HW, out_nchw, err, B);
   return check_launch("range_decode");
 }
 

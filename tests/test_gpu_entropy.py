@@ -133,3 +133,38 @@ def test_container_round_trip(model):
         entropy.unpack_container(blob[:-1])
     with pytest.raises(ValueError):
         entropy.unpack_container(b"nope" + blob)
+
+
+@pytest.mark.parametrize("spread", [4, 40, 120])
+def test_decoder_with_wide_supports(spread):
+    """Supports wider than one 64-entry table segment (L up to 261) decode exactly."""
+    from dsic_amd import entropy
+    rng = np.random.default_rng(spread)
+    B, M, N, Hy, Wy = 2, 6, 3, 5, 7
+    y = np.rint(rng.normal(size=(B, M, Hy, Wy)) * spread).astype(np.float32)
+    z = np.rint(rng.normal(size=(B, N, 2, 2)) * spread).astype(np.float32)
+    sy = rng.uniform(0.5 * spread, 1.5 * spread, (B, M)).astype(np.float32)
+    ny = rng.uniform(2.0, 30.0, (B, M)).astype(np.float32)
+    sz = rng.uniform(0.5 * spread, 1.5 * spread, N).astype(np.float32)
+    want = E.compress(y, z, sy, ny, sz, tail=10)
+    c = entropy.compress_latents(torch.from_numpy(y).cuda(), torch.from_numpy(z).cuda(), torch.from_numpy(sy).cuda(),
+                                 torch.from_numpy(ny).cuda(), torch.from_numpy(sz).cuda(), tail=10, Lmax=1000)
+    assert int(c["err"].item()) == 0
+    lens = c["lengths"].cpu().numpy()
+    raw = c["bytes"].cpu().numpy()
+    for b in range(B):
+        assert raw[b, :lens[b, 0]].tobytes() == want["strings"][b][0]
+        assert raw[b, c["cap_z"]:c["cap_z"] + lens[b, 1]].tobytes() == want["strings"][b][1]
+    # decode the y strings on the GPU with the same tables
+    from dsic_amd import lib as _lib
+    from dsic_amd.ops import _p, _stream
+    y_hat = torch.empty((B, M, Hy, Wy), device="cuda")
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ybytes = c["bytes"][:, c["cap_z"]:].contiguous()
+    ylen = c["lengths"][:, 1].contiguous()
+    _lib.check(_lib.load().dsic_range_decode(_p(ybytes), ybytes.shape[1], _p(ylen), 1, 0, _p(c["meta"]), 0,
+                                             _p(c["tab_y"]), 1000, B, M, Hy * Wy, _p(y_hat), _p(err), _stream()),
+               "range_decode")
+    assert int(err.item()) == 0
+    assert torch.equal(y_hat.cpu(), torch.from_numpy(y))
+    assert int(c["meta"][:, 1].max()) > (64 if spread >= 40 else 0)
