@@ -1,0 +1,76 @@
+"""BASELINE.json full-size configurations through size-independent properties
+(the oracle would need minutes per batch on the CPU): batch invariance, determinism,
+encode -> decode round trip, estimate vs coded size, and one 512x512x4 patch against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from dsic_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(in_ch=3):
+    from dsic_amd.model import CompressionModel
+    m = CompressionModel(N=128, M=192, spatial_params=False, min_nu=2, max_nu=100.0, in_ch=in_ch)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in S.make_state_dict(seed=1, in_ch=in_ch).items()}, strict=True)
+    return m.cuda().eval()
+
+
+def test_config3_batch64_256x256_properties():
+    from dsic_amd import entropy, metrics
+    m = _model()
+    x = torch.from_numpy(S.make_patches(0, 64, 256, 256)).cuda()
+    out = m(x, quant_mode="round")
+    # determinism: a second pass is bit-identical
+    out2 = m(x, quant_mode="round")
+    for k in ("x_hat", "y", "z", "nll_y", "nll_z"):
+        assert torch.equal(out[k], out2[k]), k
+    assert torch.equal(out.sums, out2.sums)
+    # batch invariance: patches are independent - image 17 alone gives the same bits
+    solo = m(x[17:18].contiguous(), quant_mode="round")
+    assert torch.equal(solo["y_tilde"][0], out["y_tilde"][17])
+    assert torch.equal(solo["x_hat"][0], out["x_hat"][17])
+    assert abs(float(solo.sums.sum()) - float(out.sums[17].sum())) < 1e-6
+    # shards reproduce their slice of the global batch: ranks 0/1 of a 2-GPU job
+    half = torch.from_numpy(S.make_patches(32, 32, 256, 256)).cuda()
+    assert torch.equal(m(half, quant_mode="round")["y_tilde"], out["y_tilde"][32:])
+    # rate terms are consistent: sums == reductions of the returned tensors, bpp in a sane range
+    s_y = out["nll_y"].double().sum(dim=(1, 2, 3))
+    assert float((s_y - out.sums[:, 0]).abs().max()) < 1e-2
+    bpp = out.sums.sum(dim=1) / 65536.0
+    assert 2.0 < float(bpp.min()) and float(bpp.max()) < 3.2
+    # quantised latents are integers; round(y) == y_tilde
+    assert torch.equal(out["y_tilde"], torch.round(out["y"]))
+    # encode -> decode round trip over the whole batch: the coded strings reproduce x_hat exactly
+    c = entropy.custom_compress(m, x)
+    x_hat = entropy.custom_decompress(m, entropy.unpack_container(entropy.pack_container(c)))
+    assert torch.equal(x_hat, out["x_hat"].clamp(0, 1))
+    est_bits = float(out.sums.sum())
+    real_bits = 8.0 * sum(len(s) for e in c["strings"] for s in e)
+    assert 0.99 * est_bits < real_bits < 1.02 * est_bits
+    # MS-SSIM of the batch == mean of per-image values, identical images give 1
+    ms = metrics.ms_ssim_per_image(out["x_hat"], x, clamp_x=True)
+    assert ms.shape == (64,) and float(ms.min()) > 0.0 and float(ms.max()) < 1.0
+    assert abs(metrics.ms_ssim(out["x_hat"].clamp(0, 1), x, data_range=1.0, weights=(0.3, 0.5, 0.2)).item()
+               - float(ms.mean())) < 1e-6
+
+
+def test_config5_512x512x4_patch_vs_oracle():
+    """One multi-band 512x512x4 patch (config 5 shape) against the oracle on the host."""
+    from oracle import ref_model as O
+    m = _model(in_ch=4)
+    x = torch.from_numpy(S.make_patches(900, 1, 512, 512, 4))
+    out = m(x.cuda(), quant_mode="round")
+    ref = O.forward(S.make_state_dict(seed=1, in_ch=4), x, "round")
+    assert out["y_tilde"].shape == (1, 192, 32, 32) and out["z_tilde"].shape == (1, 128, 8, 8)
+    assert int((out["y_tilde"].cpu() != ref["y_tilde"]).sum()) <= 4
+    bpp = float(out.sums.sum()) / (512 * 512)
+    bpp_ref = float(ref["nll_y"].double().sum() + ref["nll_z"].double().sum()) / (512 * 512)
+    assert abs(bpp - bpp_ref) < 1e-4
+    assert out["x_hat"].shape == (1, 4, 512, 512)
+    assert float((out["x_hat"].cpu() - ref["x_hat"]).abs().max()) < 5e-3   # a flipped latent moves x_hat locally
+    # batch of 2 at this size: invariance
+    x2 = torch.from_numpy(S.make_patches(900, 2, 512, 512, 4)).cuda()
+    out2 = m(x2, quant_mode="round")
+    assert torch.equal(out2["y_tilde"][0], out["y_tilde"][0])
