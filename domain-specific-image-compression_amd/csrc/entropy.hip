@@ -133,7 +133,7 @@ __global__ __launch_bounds__(1024) void range_encode_kernel(
     const float* __restrict__ y, const float* __restrict__ z, const int* __restrict__ meta,
     const uint16_t* __restrict__ tab_y, const uint16_t* __restrict__ tab_z, int Lmax, int M, int HWy,
     int N, int HWz, uint8_t* __restrict__ out, int64_t cap_y, int64_t cap_z,
-    int* __restrict__ lengths, int* __restrict__ err, int nstreams) {
+    int* __restrict__ lengths, int* __restrict__ err, int nstreams, int per_element_y) {
   const int lane = threadIdx.x & 63;
   const int sid = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
   if (sid >= nstreams) return;
@@ -141,7 +141,9 @@ __global__ __launch_bounds__(1024) void range_encode_kernel(
   const int C = which ? M : N, HW = which ? HWy : HWz;
   const int64_t n = (int64_t)C * HW;
   const float* sym = which ? y + (size_t)b * n : z + (size_t)b * n;
-  const uint16_t* tab = (which ? tab_y + (size_t)b * M * Lmax : tab_z + (size_t)b * N * Lmax);
+  const bool per_element = which && per_element_y;  // spatial_params: one table row per y symbol
+  const uint16_t* tab = (which ? tab_y + (size_t)b * (per_element ? (size_t)M * HWy : (size_t)M) * Lmax
+                               : tab_z + (size_t)b * N * Lmax);
   const int smin = meta[4 * b + (which ? 0 : 2)], L = meta[4 * b + (which ? 1 : 3)];
   const int64_t stride = cap_z + cap_y;  // per image: [z bytes | y bytes], zero-initialised by the caller
   uint32_t* dst32 = (uint32_t*)(out + (size_t)b * stride + (which ? cap_z : 0));
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(1024) void range_encode_kernel(
       atomicOr(err, 2);
       sc = 0;
     }
-    const uint16_t* t = tab + (size_t)c * Lmax;
+    const uint16_t* t = tab + (size_t)(per_element ? g : (int64_t)c) * Lmax;
     const uint32_t c_low = t[sc];
     const uint32_t c_high = (sc == L - 1) ? 0x10000u : (uint32_t)t[sc + 1];
     return c_low | ((c_high - 1u) << 16);
@@ -274,7 +276,8 @@ __global__ __launch_bounds__(256) void range_decode_kernel(const uint8_t* __rest
                                                            int meta_off,
                                                            const uint16_t* __restrict__ tables, int Lmax,
                                                            int C, int HW, float* __restrict__ out,
-                                                           int* __restrict__ err, int B) {
+                                                           int* __restrict__ err, int B,
+                                                           int per_element) {
   const int lane = threadIdx.x & 63;
   const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
   if (b >= B) return;
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(256) void range_decode_kernel(const uint8_t* __rest
     if (lane == 0) atomicOr(err, 1);
     return;
   }
-  const uint16_t* gt = tables + (size_t)b * C * Lmax;
+  const uint16_t* gt = tables + (size_t)b * (per_element ? (size_t)C * HW : (size_t)C) * Lmax;
   const uint32_t* src32 = (const uint32_t*)(in + (size_t)b * stride);  // stride is a multiple of 4
   const int nbytes = lengths[b * lstride + loff];
   const int ndw = (nbytes + 3) >> 2;
@@ -330,10 +333,24 @@ __global__ __launch_bounds__(256) void range_decode_kernel(const uint8_t* __rest
   uint32_t value = take(16);
   value = (value << 16) | take(16);
 
-  const int nseg = (L + 63) >> 6;  // table entries per channel, 64 per register
-  for (int c = 0; c < C; ++c) {
-    const uint16_t* t = gt + (size_t)c * Lmax;
-    for (int i = 0; i < HW; ++i) {
+  const int nseg = (L + 63) >> 6;  // table entries per row, 64 per register
+  // Table row of the current symbol: per channel (row changes every HW symbols) or per element
+  // (spatial_params: a row per symbol).  Segment 0 of the NEXT row is prefetched while the
+  // current symbol is decoded, so the row load never sits on the serial chain.
+  // row index of symbol g, tracked incrementally (no 64-bit division on the serial chain)
+  int64_t row = 0;   // row of the current symbol
+  int in_row = 0;    // symbols already decoded from the current per-channel row
+  auto load_seg = [&](const uint16_t* t, int seg) -> uint32_t {
+    const int k = seg * 64 + lane;
+    return k < L ? (uint32_t)t[k] : 0x10000u;  // entries past L act as c[L] = 65536
+  };
+  uint32_t ck0 = load_seg(gt, 0);
+  for (int64_t g = 0; g < n; ++g) {
+    {
+      const uint16_t* t = gt + (size_t)row * Lmax;
+      const bool new_row = per_element || in_row + 1 == HW;
+      uint32_t ck0_next = ck0;
+      if (new_row && g + 1 < n) ck0_next = load_seg(gt + (size_t)(row + 1) * Lmax, 0);
       const uint32_t d = value - low;
       const uint32_t r = high - low;  // span - 1
       // s = (number of k in [0,L) with floor(span*c[k]/2^16) <= d) - 1
@@ -342,7 +359,7 @@ __global__ __launch_bounds__(256) void range_decode_kernel(const uint8_t* __rest
       bool carry = false;  // the previous 64-entry segment was entirely <= count
       for (int seg = 0; seg < nseg; ++seg) {
         const int k = seg * 64 + lane;
-        const uint32_t ck = k < L ? (uint32_t)t[k] : 0x10000u;  // entries past L act as c[L] = 65536
+        const uint32_t ck = seg == 0 ? ck0 : load_seg(t, seg);
         const uint32_t bound = (uint32_t)(((uint64_t)r * ck + ck) >> 16);
         const int hits = __popcll(__ballot(k < L && bound <= d));
         if (hits == 0) {  // only after a full segment (c[0] = 0 always hits)
@@ -365,8 +382,15 @@ __global__ __launch_bounds__(256) void range_decode_kernel(const uint8_t* __rest
           c_high = 0x10000u;
         }
       }
+      ck0 = ck0_next;
+      if (new_row) {
+        row += 1;
+        in_row = 0;
+      } else {
+        in_row += 1;
+      }
       const int sidx = cnt - 1;
-      if (lane == 0) dst[(size_t)c * HW + i] = (float)(sidx + smin);
+      if (lane == 0) dst[g] = (float)(sidx + smin);
       // interval update + renormalisation (same arithmetic as the encoder)
       const uint32_t hi_add = (uint32_t)(((uint64_t)r * c_high + c_high) >> 16);
       const uint32_t lo_add = (uint32_t)(((uint64_t)r * c_low + c_low) >> 16);
@@ -398,6 +422,8 @@ extern "C" int dsic_latent_support(const float* y_nchw, const float* z_nchw, int
   return check_launch("latent_support");
 }
 
+// C counts table rows per image: channels, or channels*HW in per-element mode (sigma/nu then
+// hold one value per latent element, NCHW order = symbol order).
 static int tables_launch(bool student, const float* sigma, const float* nu, int per_image,
                          const int* meta, int meta_off, uint16_t* tables, int B, int C, int Lmax,
                          int* err, hipStream_t st) {
@@ -421,15 +447,16 @@ extern "C" int dsic_cdf_tables_gauss(const float* sigma_z, const int* meta, uint
 }
 
 extern "C" int dsic_cdf_tables_student(const float* sigma, const float* nu, const int* meta,
-                                       uint16_t* tables, int B, int M, int Lmax, int* err,
+                                       uint16_t* tables, int B, int rows, int Lmax, int* err,
                                        void* stream) {
-  return tables_launch(true, sigma, nu, 1, meta, 0, tables, B, M, Lmax, err, (hipStream_t)stream);
+  return tables_launch(true, sigma, nu, 1, meta, 0, tables, B, rows, Lmax, err, (hipStream_t)stream);
 }
 
 extern "C" int dsic_range_encode(const float* y_nchw, const float* z_nchw, const int* meta,
                                  const uint16_t* tab_y, const uint16_t* tab_z, int Lmax, int B, int M,
                                  int HWy, int N, int HWz, uint8_t* out, int64_t cap_y, int64_t cap_z,
-                                 int* lengths, int* err, int streams_per_wg, void* stream) {
+                                 int* lengths, int* err, int streams_per_wg, int per_element_y,
+                                 void* stream) {
   DSIC_REQUIRE(y_nchw && z_nchw && meta && tab_y && tab_z && out && lengths && err,
                "range_encode: null pointer");
   DSIC_REQUIRE(B > 0 && M > 0 && N > 0 && HWy > 0 && HWz > 0, "range_encode: empty latent");
@@ -439,20 +466,20 @@ extern "C" int dsic_range_encode(const float* y_nchw, const float* z_nchw, const
   hipLaunchKernelGGL(range_encode_kernel, dim3(ceil_div(2 * B, streams_per_wg)), dim3(64 * streams_per_wg), 0,
                      (hipStream_t)stream,
                      y_nchw, z_nchw, meta, tab_y, tab_z, Lmax, M, HWy, N, HWz, out, cap_y, cap_z, lengths,
-                     err, 2 * B);
+                     err, 2 * B, per_element_y ? 1 : 0);
   return check_launch("range_encode");
 }
 
 extern "C" int dsic_range_decode(const uint8_t* in, int64_t stride, const int* lengths, int lstride,
                                  int loff, const int* meta, int meta_off, const uint16_t* tables,
-                                 int Lmax, int B, int C, int HW, float* out_nchw, int* err,
-                                 void* stream) {
+                                 int Lmax, int B, int C, int HW, int per_element, float* out_nchw,
+                                 int* err, void* stream) {
   DSIC_REQUIRE(in && lengths && meta && tables && out_nchw && err, "range_decode: null pointer");
   DSIC_REQUIRE(B > 0 && C > 0 && HW > 0 && Lmax >= 1, "range_decode: bad argument");
   DSIC_REQUIRE(meta_off == 0 || meta_off == 2, "range_decode: meta_off must be 0 (y) or 2 (z)");
   DSIC_REQUIRE(stride % 4 == 0, "range_decode: stride must be a multiple of 4");
   hipLaunchKernelGGL(range_decode_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, (hipStream_t)stream, in, stride,
-                     lengths, lstride, loff, meta, meta_off, tables, Lmax, C, HW, out_nchw, err, B);
+                     lengths, lstride, loff, meta, meta_off, tables, Lmax, C, HW, out_nchw, err, B, per_element ? 1 : 0);
   return check_launch("range_decode");
 }
 

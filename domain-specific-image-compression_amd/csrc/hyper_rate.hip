@@ -96,11 +96,11 @@ __global__ __launch_bounds__(256) void rate_kernel(
     const float* __restrict__ z_noisy, const float* __restrict__ sigma, const float* __restrict__ nu,
     const float* __restrict__ z_log_sigma, float* __restrict__ y_hat, float* __restrict__ y_tilde,
     float* __restrict__ z_tilde, float* __restrict__ nll_y, float* __restrict__ nll_z,
-    double* __restrict__ sums, int HWy, int M, int HWz, int N) {
+    double* __restrict__ sums, int HWy, int M, int HWz, int N, int per_element) {
   __shared__ float s_sig[MAXM], s_nu[MAXM], s_logc[MAXM];
   __shared__ double scratch[4];
   const int b = blockIdx.x, tid = threadIdx.x;
-  for (int c = tid; c < M; c += 256) {
+  for (int c = tid; c < M && !per_element; c += 256) {
     // distributions.py:25-29; the channel constant is evaluated in fp64 and
     // rounded once (the reference evaluates it in fp32 per element).
     const float sg = fminf(fmaxf(sigma[(size_t)b * M + c], 1e-3f), 1e3f);
@@ -119,9 +119,21 @@ __global__ __launch_bounds__(256) void rate_kernel(
     const float v = y[ybase + i];
     const float r = rintf(v);  // torch.round: half to even
     const float xt = y_noisy ? y_noisy[ybase + i] : r;
-    const float q = xt / s_sig[c];
+    float sg, nv, lc;
+    if (per_element) {  // spatial_params (model.py:49-51): sigma, nu are NCHW [B,M,HWy]
+      const size_t e = ((size_t)b * M + c) * HWy + p;
+      sg = fminf(fmaxf(sigma[e], 1e-3f), 1e3f);
+      nv = fminf(fmaxf(nu[e], 2.0f), 100.0f);
+      const double nd = (double)nv;
+      lc = (float)(lgamma((nd + 1.0) * 0.5) - lgamma(nd * 0.5) - 0.5 * log(nd * PI_D) - log((double)sg));
+    } else {
+      sg = s_sig[c];
+      nv = s_nu[c];
+      lc = s_logc[c];
+    }
+    const float q = xt / sg;
     const float quad = q * q;
-    const float logp = s_logc[c] - ((s_nu[c] + 1.0f) / 2.0f) * log1pf(quad / s_nu[c]);
+    const float logp = lc - ((nv + 1.0f) / 2.0f) * log1pf(quad / nv);
     const float bits = -logp * LOG2E_F;
     y_hat[ybase + i] = r;
     const size_t o = ((size_t)b * M + c) * HWy + p;
@@ -192,6 +204,21 @@ __global__ void gaussian_bits_kernel(const float* __restrict__ x, const float* _
   out[i] = -logp * LOG2E_F;
 }
 
+// spatial_params branch of model.py:49-51: sigma = exp(log_sigma), nu = clamp(exp(log_nu)),
+// from the NHWC head outputs to the reference's NCHW tensors.
+__global__ void sigma_nu_spatial_kernel(const float* __restrict__ ls, const float* __restrict__ ln,
+                                        float* __restrict__ sigma, float* __restrict__ nu, int HW, int M,
+                                        float min_nu, float max_nu, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // NCHW index
+  if (i >= total) return;
+  const int p = i % HW;
+  const int c = (i / HW) % M;
+  const int64_t b = i / ((int64_t)HW * M);
+  const size_t src = ((size_t)b * HW + p) * M + c;
+  sigma[i] = expf(ls[src]);
+  nu[i] = fminf(fmaxf(expf(ln[src]), min_nu), max_nu);
+}
+
 __global__ void round_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t total) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < total) out[i] = rintf(x[i]);
@@ -216,6 +243,18 @@ extern "C" int dsic_gaussian_bits(const float* x, const float* log_sigma, float*
   hipLaunchKernelGGL(gaussian_bits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, x, log_sigma, out, C, HW, n);
   return check_launch("gaussian_bits");
+}
+
+extern "C" int dsic_sigma_nu_spatial(const float* log_sigma_nhwc, const float* log_nu_nhwc, float* sigma_nchw,
+                                     float* nu_nchw, int B, int HW, int M, float min_nu, float max_nu,
+                                     void* stream) {
+  DSIC_REQUIRE(log_sigma_nhwc && log_nu_nhwc && sigma_nchw && nu_nchw && B > 0 && HW > 0 && M > 0,
+               "sigma_nu_spatial: bad argument");
+  const int64_t total = (int64_t)B * HW * M;
+  hipLaunchKernelGGL(sigma_nu_spatial_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, log_sigma_nhwc, log_nu_nhwc, sigma_nchw, nu_nchw, HW, M, min_nu, max_nu,
+                     total);
+  return check_launch("sigma_nu_spatial");
 }
 
 extern "C" int dsic_round(const float* x, float* out, int64_t n, void* stream) {
@@ -244,7 +283,7 @@ extern "C" int dsic_rate(const float* y_nhwc, const float* z_nhwc, const float* 
                          const float* z_noisy_nhwc, const float* sigma, const float* nu,
                          const float* z_log_sigma, float* y_hat_nhwc, float* y_tilde_nchw,
                          float* z_tilde_nchw, float* nll_y_nchw, float* nll_z_nchw, double* sums,
-                         int B, int HWy, int M, int HWz, int N, void* stream) {
+                         int B, int HWy, int M, int HWz, int N, int per_element, void* stream) {
   DSIC_REQUIRE(y_nhwc && z_nhwc && sigma && nu && z_log_sigma && y_hat_nhwc && y_tilde_nchw &&
                    z_tilde_nchw && nll_y_nchw && nll_z_nchw && sums, "rate: null pointer");
   DSIC_REQUIRE(B > 0 && HWy > 0 && HWz > 0, "rate: empty tensor");
@@ -252,7 +291,7 @@ extern "C" int dsic_rate(const float* y_nhwc, const float* z_nhwc, const float* 
   DSIC_REQUIRE((int64_t)HWy * M < ((int64_t)1 << 31), "rate: latent too large");
   hipLaunchKernelGGL(rate_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, y_nhwc, z_nhwc,
                      y_noisy_nhwc, z_noisy_nhwc, sigma, nu, z_log_sigma, y_hat_nhwc, y_tilde_nchw,
-                     z_tilde_nchw, nll_y_nchw, nll_z_nchw, sums, HWy, M, HWz, N);
+                     z_tilde_nchw, nll_y_nchw, nll_z_nchw, sums, HWy, M, HWz, N, per_element ? 1 : 0);
   return check_launch("rate");
 }
 

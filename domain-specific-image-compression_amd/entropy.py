@@ -52,9 +52,12 @@ def latent_support(y_tilde, z_tilde, tail=10):
 
 
 def cdf_tables(sigma_y, nu_y, sigma_z, meta, Lmax=DEFAULT_LMAX, err=None):
-    """-> (tab_y [B,M,Lmax], tab_z [B,N,Lmax]) uint16 coder tables (:43-47, :55-61, :17-23)."""
-    sy = _f32c(sigma_y, "cdf_tables")
-    ny = _f32c(nu_y, "cdf_tables")
+    """-> (tab_y [B,rows,Lmax], tab_z [B,N,Lmax]) uint16 coder tables (:43-47, :55-61, :17-23).
+
+    sigma_y/nu_y: [B,M] (one row per channel) or [B,M,Hy,Wy] (spatial_params: one row per latent
+    element, NCHW order = symbol order)."""
+    sy = _f32c(sigma_y, "cdf_tables").reshape(sigma_y.shape[0], -1)
+    ny = _f32c(nu_y, "cdf_tables").reshape(nu_y.shape[0], -1)
     sz = _f32c(sigma_z, "cdf_tables")
     B, M = sy.shape
     N = sz.numel()
@@ -89,6 +92,7 @@ def compress_latents(y_tilde, z_tilde, sigma_y, nu_y, sigma_z, tail=10, Lmax=DEF
     B, M, Hy, Wy = y.shape
     _, N, Hz, Wz = z.shape
     dev = y.device
+    per_element = sigma_y.dim() == 4        # spatial_params: a table row per latent element
     meta = latent_support(y, z, tail)
     tab_y, tab_z, err = cdf_tables(sigma_y, nu_y, sigma_z, meta, Lmax)
     cap_y, cap_z = _cap(M * Hy * Wy), _cap(N * Hz * Wz)
@@ -96,7 +100,7 @@ def compress_latents(y_tilde, z_tilde, sigma_y, nu_y, sigma_z, tail=10, Lmax=DEF
     lengths = torch.zeros((B, 2), dtype=torch.int32, device=dev)
     _lib.check(_lib.load().dsic_range_encode(_p(y), _p(z), _p(meta), _p(tab_y), _p(tab_z), Lmax, B, M, Hy * Wy,
                                              N, Hz * Wz, _p(out), cap_y, cap_z, _p(lengths), _p(err),
-                                             int(streams_per_wg), _stream()), "range_encode")
+                                             int(streams_per_wg), int(per_element), _stream()), "range_encode")
     return {"bytes": out, "lengths": lengths, "meta": meta, "cap_z": cap_z, "cap_y": cap_y,
             "tab_y": tab_y, "tab_z": tab_z, "err": err, "shape_y": list(y.shape), "shape_z": list(z.shape)}
 
@@ -164,8 +168,17 @@ class AsyncCompressor:
 
 
 def _per_channel(t):
-    """[B,M,H,W] spatially constant (expanded) or [B,M] -> contiguous [B,M]."""
-    return (t[:, :, 0, 0] if t.dim() == 4 else t).contiguous()
+    """[B,M,H,W] spatially constant (expanded) -> contiguous [B,M]; per-element tensors
+    (spatial_params) and [B,M] pass through."""
+    if t.dim() == 4 and t.stride(2) == 0 and t.stride(3) == 0:
+        return t[:, :, 0, 0].contiguous()
+    return t.contiguous()
+
+
+def _tight_lmax(meta, minimum=32):
+    """Support width of this batch (host sync): keeps per-element tables small."""
+    L = int(meta[:, [1, 3]].max().item())
+    return max(minimum, (L + 7) // 8 * 8)
 
 
 @torch.no_grad()
@@ -174,6 +187,10 @@ def custom_compress(model, x, tail=10, Lmax=DEFAULT_LMAX):
     strings [[z_bytes, y_bytes], ...], shape_y, shape_z, min_y, max_y, min_z, max_z."""
     out = model(x, quant_mode="round")
     sigma_z = torch.exp(model.z_prior.log_sigma)                       # :32 (no clamp)
+    if getattr(model, "spatial_params", False):
+        # one table row per latent element: size the rows to the actual support (the reference
+        # reads min/max on the host here too, :39-40,52-53)
+        Lmax = min(1000, _tight_lmax(latent_support(out["y_tilde"], out["z_tilde"], tail)))
     while True:
         c = compress_latents(out["y_tilde"], out["z_tilde"], _per_channel(out["sigma"]),
                              _per_channel(out["nu"]), sigma_z, tail, Lmax)
@@ -221,7 +238,8 @@ def custom_decompress(model, compressed, Lmax=None):
                          compressed["min_z"][b], compressed["max_z"][b] - compressed["min_z"][b] + 1]
                         for b in range(B)], dtype=np.int32)
     if Lmax is None:
-        Lmax = max(DEFAULT_LMAX, int(meta_np[:, [1, 3]].max()))
+        Lmax = int(meta_np[:, [1, 3]].max())
+        Lmax = (Lmax + 7) // 8 * 8 if getattr(model, "spatial_params", False) else max(DEFAULT_LMAX, Lmax)
     meta = torch.from_numpy(meta_np).to(dev)
     err = torch.zeros(1, dtype=torch.int32, device=dev)
     L = _lib.load()
@@ -232,16 +250,18 @@ def custom_decompress(model, compressed, Lmax=None):
     zbuf, zlen, zstride = _upload_strings(strings, 0, dev)
     z_hat = torch.empty((B, N, Hz, Wz), dtype=torch.float32, device=dev)
     _lib.check(L.dsic_range_decode(_p(zbuf), zstride, _p(zlen), 1, 0, _p(meta), 2, _p(tab_z), Lmax, B, N,
-                                   Hz * Wz, _p(z_hat), _p(err), _stream()), "range_decode(z)")
+                                   Hz * Wz, 0, _p(z_hat), _p(err), _stream()), "range_decode(z)")
     # :100-106: hyper-synthesis on the decoded z
     (_, _, sigma_y, nu_y), _ = model.h_s.params_nhwc(ops.nchw_to_nhwc(z_hat), model.min_nu, model.max_nu)
-    tab_y = torch.zeros((B, M, Lmax), dtype=torch.uint16, device=dev)
-    _lib.check(L.dsic_cdf_tables_student(_p(sigma_y), _p(nu_y), _p(meta), _p(tab_y), B, M, Lmax, _p(err),
-                                         _stream()), "cdf_tables_student")
+    per_element = int(getattr(model, "spatial_params", False))
+    rows = M * Hy * Wy if per_element else M
+    tab_y = torch.zeros((B, rows, Lmax), dtype=torch.uint16, device=dev)
+    _lib.check(L.dsic_cdf_tables_student(_p(sigma_y.contiguous()), _p(nu_y.contiguous()), _p(meta), _p(tab_y), B,
+                                         rows, Lmax, _p(err), _stream()), "cdf_tables_student")
     ybuf, ylen, ystride = _upload_strings(strings, 1, dev)
     y_hat = torch.empty((B, M, Hy, Wy), dtype=torch.float32, device=dev)
     _lib.check(L.dsic_range_decode(_p(ybuf), ystride, _p(ylen), 1, 0, _p(meta), 0, _p(tab_y), Lmax, B, M,
-                                   Hy * Wy, _p(y_hat), _p(err), _stream()), "range_decode(y)")
+                                   Hy * Wy, per_element, _p(y_hat), _p(err), _stream()), "range_decode(y)")
     _check_err(err, "custom_decompress")
     x_hat = model.g_s.forward_nhwc(ops.nchw_to_nhwc(y_hat))            # :120
     return x_hat.clamp(0, 1)                                           # :123

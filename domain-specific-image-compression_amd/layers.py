@@ -376,23 +376,29 @@ class HyperSynthesis(nn.Module):
 
     def __init__(self, N=128, M=128, spatial_params=False):
         super().__init__()
-        if spatial_params:
-            raise NotImplementedError(
-                "spatial_params=True (layers.py:127-129) is outside this round's hot path; "
-                "every reference script runs spatial_params=False (config.py:25)")
         self.spatial_params = spatial_params
         self.N, self.M = N, M
         self.h_s = _Chain(
             ConvTranspose2d(N, N, 5, 2, 2, output_padding=1), nn.ReLU(inplace=True),
             ConvTranspose2d(N, N, 5, 2, 2, output_padding=1), nn.ReLU(inplace=True),
         )
-        self.pool = nn.AdaptiveAvgPool2d(1)
-        self.mlp_sigma = nn.Sequential(Conv2d(N, N, 1), nn.ReLU(), Conv2d(N, M, 1))
-        self.mlp_nu = nn.Sequential(Conv2d(N, N, 1), nn.ReLU(), Conv2d(N, M, 1))
+        if spatial_params:      # layers.py:127-129: per-element heads
+            self.to_sigma = conv(N, M, 3, 1)
+            self.to_nu = conv(N, M, 3, 1)
+        else:                   # layers.py:130-139: global per-channel heads
+            self.pool = nn.AdaptiveAvgPool2d(1)
+            self.mlp_sigma = nn.Sequential(Conv2d(N, N, 1), nn.ReLU(), Conv2d(N, M, 1))
+            self.mlp_nu = nn.Sequential(Conv2d(N, N, 1), nn.ReLU(), Conv2d(N, M, 1))
 
     def params_nhwc(self, z_hat_nhwc, min_nu, max_nu, taps=None):
-        """-> (log_sigma, log_nu, sigma, nu) each [B,M], plus t's spatial size."""
+        """spatial_params=False: -> ((log_sigma, log_nu, sigma, nu) each [B,M], (Ht, Wt)).
+        spatial_params=True:  -> ((log_sigma, log_nu) NHWC [B,Ht,Wt,M], sigma, nu NCHW), (Ht, Wt)."""
         t = self.h_s.forward_nhwc(z_hat_nhwc, taps)
+        if self.spatial_params:
+            ls = self.to_sigma.run_nhwc(t)
+            ln = self.to_nu.run_nhwc(t)
+            sigma, nu = ops.sigma_nu_spatial(ls, ln, min_nu, max_nu)
+            return (ls, ln, sigma, nu), (t.shape[1], t.shape[2])
         s0, s2 = self.mlp_sigma[0], self.mlp_sigma[2]
         n0, n2 = self.mlp_nu[0], self.mlp_nu[2]
         outs = ops.hyper_params(t, s0.packed(), s0.bias, s2.packed(), s2.bias, n0.packed(), n0.bias,
@@ -403,6 +409,8 @@ class HyperSynthesis(nn.Module):
     def forward(self, z):
         # clamp bounds are irrelevant for the log outputs returned here
         (log_sigma, log_nu, _, _), (Ht, Wt) = self.params_nhwc(_to_nhwc(z), 0.0, float("inf"))
+        if self.spatial_params:
+            return ops.nhwc_to_nchw(log_sigma), ops.nhwc_to_nchw(log_nu)
         B = z.shape[0]
         return (log_sigma.view(B, self.M, 1, 1).expand(-1, -1, Ht, Wt),
                 log_nu.view(B, self.M, 1, 1).expand(-1, -1, Ht, Wt))

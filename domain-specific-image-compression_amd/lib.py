@@ -41,7 +41,8 @@ SIGNATURES = {
     "dsic_conv_transpose2d_image": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "dsic_hyper_params": (c_int, [_P] * 13 + [c_int, c_int, c_int, c_int, ctypes.c_float,
                                      ctypes.c_float, _P]),
-    "dsic_rate": (c_int, [_P] * 13 + [c_int, c_int, c_int, c_int, c_int, _P]),
+    "dsic_rate": (c_int, [_P] * 13 + [c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "dsic_sigma_nu_spatial": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, ctypes.c_float, ctypes.c_float, _P]),
     "dsic_student_t_bits": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P]),
     "dsic_gaussian_bits": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "dsic_round": (c_int, [_P, _P, c_int64, _P]),
@@ -56,11 +57,11 @@ SIGNATURES = {
     "dsic_cdf_tables_gauss": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P]),
     "dsic_cdf_tables_student": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P]),
     "dsic_range_encode": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P,
-                                  c_int64, c_int64, _P, _P, c_int, _P]),
+                                  c_int64, c_int64, _P, _P, c_int, c_int, _P]),
     "dsic_stream_create_masked": (c_int, [_P, c_int, _P]),
     "dsic_stream_destroy": (c_int, [_P]),
     "dsic_range_decode": (c_int, [_P, c_int64, _P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int,
-                                  c_int, _P, _P, _P]),
+                                  c_int, c_int, _P, _P, _P]),
     "dsic_host_normal_cdf": (ctypes.c_double, [ctypes.c_double]),
     "dsic_host_student_t_cdf": (ctypes.c_double, [ctypes.c_double, ctypes.c_double]),
     "dsic_host_cdf_table": (c_int, [c_int, ctypes.c_float, ctypes.c_float, c_int, c_int, _P]),

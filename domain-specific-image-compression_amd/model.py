@@ -85,8 +85,8 @@ class CompressionModel(nn.Module):
             "nll_z": r["nll_z"],
             "y": ops.nhwc_to_nchw(y), "y_tilde": r["y_tilde"],
             "z": ops.nhwc_to_nchw(z), "z_tilde": r["z_tilde"],
-            "sigma": sigma.view(B, self.M, 1, 1).expand(-1, -1, Hy, Wy),
-            "nu": nu.view(B, self.M, 1, 1).expand(-1, -1, Hy, Wy),
+            "sigma": sigma if self.spatial_params else sigma.view(B, self.M, 1, 1).expand(-1, -1, Hy, Wy),
+            "nu": nu if self.spatial_params else nu.view(B, self.M, 1, 1).expand(-1, -1, Hy, Wy),
         })
         out.sums = r["sums"]
         out.layer_taps = taps

@@ -289,9 +289,12 @@ def rate(y_nhwc, z_nhwc, sigma, nu, z_log_sigma, y_noisy=None, z_noisy=None):
     z_t = torch.empty((B, N, Hz, Wz), dtype=torch.float32, device=dev)
     nll_z = torch.empty_like(z_t)
     sums = torch.empty((B, 2), dtype=torch.float64, device=dev)
+    per_element = 1 if sigma.dim() == 4 else 0          # [B,M,Hy,Wy] (spatial_params) vs [B,M]
+    sigma = _f32c(sigma, "rate")
+    nu = _f32c(nu, "rate")
     _lib.check(_lib.load().dsic_rate(_p(y), _p(z), _p(y_noisy), _p(z_noisy), _p(sigma), _p(nu),
                                      _p(z_log_sigma), _p(y_hat), _p(y_t), _p(z_t), _p(nll_y), _p(nll_z),
-                                     _p(sums), B, Hy * Wy, M, Hz * Wz, N, _stream()), "rate")
+                                     _p(sums), B, Hy * Wy, M, Hz * Wz, N, per_element, _stream()), "rate")
     return {"y_hat_nhwc": y_hat, "y_tilde": y_t, "z_tilde": z_t, "nll_y": nll_y, "nll_z": nll_z,
             "sums": sums}
 
@@ -324,3 +327,15 @@ def gaussian_bits(x, log_sigma):
     _lib.check(_lib.load().dsic_gaussian_bits(_p(x), _p(_f32c(log_sigma, "gaussian_bits")), _p(out), B, C,
                                               H * W, _stream()), "gaussian_bits")
     return out
+
+
+def sigma_nu_spatial(log_sigma_nhwc, log_nu_nhwc, min_nu, max_nu):
+    """spatial_params head outputs (NHWC) -> sigma, nu NCHW [B,M,H,W] (model.py:49-51)."""
+    ls = _f32c(log_sigma_nhwc, "sigma_nu_spatial")
+    ln = _f32c(log_nu_nhwc, "sigma_nu_spatial")
+    B, H, W, M = ls.shape
+    sigma = torch.empty((B, M, H, W), dtype=torch.float32, device=ls.device)
+    nu = torch.empty_like(sigma)
+    _lib.check(_lib.load().dsic_sigma_nu_spatial(_p(ls), _p(ln), _p(sigma), _p(nu), B, H * W, M, float(min_nu),
+                                                 float(max_nu), _stream()), "sigma_nu_spatial")
+    return sigma, nu

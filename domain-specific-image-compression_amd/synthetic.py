@@ -52,7 +52,7 @@ def _stream_id(name: str) -> int:
     return zlib.crc32(name.encode()) & 0xFFFFFFFF
 
 
-def state_dict_spec(N: int = 128, M: int = 192, in_ch: int = 3):
+def state_dict_spec(N: int = 128, M: int = 192, in_ch: int = 3, spatial_params: bool = False):
     """[(key, shape, kind, fan_in)] in the reference's state_dict order."""
     spec = []
 
@@ -95,9 +95,13 @@ def state_dict_spec(N: int = 128, M: int = 192, in_ch: int = 3):
     # h_s  (layers.py:122-139), non-spatial heads
     convT("h_s.h_s.0", N, N, 5)
     convT("h_s.h_s.2", N, N, 5)
-    for head in ("mlp_sigma", "mlp_nu"):
-        conv(f"h_s.{head}.0", N, N, 1)
-        conv(f"h_s.{head}.2", M, N, 1)
+    if spatial_params:   # layers.py:127-129
+        conv("h_s.to_sigma", M, N, 3)
+        conv("h_s.to_nu", M, N, 3)
+    else:                # layers.py:132-139
+        for head in ("mlp_sigma", "mlp_nu"):
+            conv(f"h_s.{head}.0", N, N, 1)
+            conv(f"h_s.{head}.2", M, N, 1)
     spec.append(("z_prior.log_sigma", (N,), "logsig", 0))
     return spec
 
@@ -111,15 +115,17 @@ _WEIGHT_GAIN = {
 _BIAS_SHIFT = {
     "h_s.mlp_nu.2.bias": 1.5,
     "h_s.mlp_sigma.2.bias": 1.0,
+    "h_s.to_nu.bias": 1.5,
+    "h_s.to_sigma.bias": 1.0,
     "g_s.g_s.12.bias": 0.5,
 }
 
 
-def make_state_dict(seed: int = WEIGHT_SEED, N: int = 128, M: int = 192,
-                    in_ch: int = 3) -> "OrderedDict[str, np.ndarray]":
-    """Synthetic float32 state_dict with the reference's 90 keys."""
+def make_state_dict(seed: int = WEIGHT_SEED, N: int = 128, M: int = 192, in_ch: int = 3,
+                    spatial_params: bool = False) -> "OrderedDict[str, np.ndarray]":
+    """Synthetic float32 state_dict with the reference's keys (90 for spatial_params=False)."""
     sd = OrderedDict()
-    for key, shape, kind, fan_in in state_dict_spec(N, M, in_ch):
+    for key, shape, kind, fan_in in state_dict_spec(N, M, in_ch, spatial_params):
         n = int(np.prod(shape))
         u = hash_uniform(n, seed, _stream_id(key))
         if kind in ("w", "b"):
@@ -129,7 +135,7 @@ def make_state_dict(seed: int = WEIGHT_SEED, N: int = 128, M: int = 192,
                 v = v * np.float32(_WEIGHT_GAIN.get(key, 1.0))
             else:
                 v = v + np.float32(_BIAS_SHIFT.get(key, 0.0))
-                if key == "h_s.mlp_nu.2.bias":
+                if key in ("h_s.mlp_nu.2.bias", "h_s.to_nu.bias"):
                     # drive a few channels to both nu clamps (min_nu, max_nu)
                     v[0::37] = np.float32(-3.0)
                     v[5::41] = np.float32(6.0)

@@ -154,6 +154,7 @@ int dsic_hyper_params(const float* t_nhwc, const float* w1_sigma,
  * (distributions.py:20-31), FactorizedGaussian.neg_log2_prob
  * (distributions.py:39-46) and the per-image sums behind model.py:76.
  * y NHWC [B,HWy,M], z NHWC [B,HWz,N]; sigma, nu [B,M]; z_log_sigma [N].
+ * per_element: sigma, nu are NCHW [B,M,HWy] (spatial_params=True) instead of [B,M].
  * y_noisy/z_noisy (NHWC, may be NULL): when given they ARE y_tilde/z_tilde
  * (quant_mode="noise"), otherwise y_tilde = round(y).  Outputs: y_hat NHWC
  * (= round(y), the synthesis input), y_tilde/z_tilde/nll_y/nll_z in the
@@ -163,7 +164,14 @@ int dsic_rate(const float* y_nhwc, const float* z_nhwc,
               const float* sigma, const float* nu, const float* z_log_sigma,
               float* y_hat_nhwc, float* y_tilde_nchw, float* z_tilde_nchw,
               float* nll_y_nchw, float* nll_z_nchw, double* sums, int B,
-              int HWy, int M, int HWz, int N, void* stream);
+              int HWy, int M, int HWz, int N, int per_element, void* stream);
+
+/* spatial_params=True branch of model.py:49-51: the two 3x3 heads' NHWC outputs
+ * [B,HW,M] -> sigma = exp(log_sigma), nu = clamp(exp(log_nu), min_nu, max_nu) as
+ * NCHW [B,M,HW]; dsic_rate / dsic_cdf_tables_student then take per_element = 1. */
+int dsic_sigma_nu_spatial(const float* log_sigma_nhwc, const float* log_nu_nhwc,
+                          float* sigma_nchw, float* nu_nchw, int B, int HW, int M,
+                          float min_nu, float max_nu, void* stream);
 
 /* StudentT.neg_log2_prob (distributions.py:20-31) elementwise on NCHW x[n].
  * per_channel=1: sigma/nu are [B*C] (spatially constant, HW elements each);
@@ -225,20 +233,23 @@ int dsic_latent_support(const float* y_nchw, const float* z_nchw, int* meta,
 int dsic_cdf_tables_gauss(const float* sigma_z, const int* meta,
                           uint16_t* tables, int B, int N, int Lmax, int* err,
                           void* stream);
-/* :55-61 Student-t PMF tables; sigma, nu [B][M] (spatially constant). */
+/* :55-61 Student-t PMF tables; sigma, nu [B][rows]: rows = M for spatially constant
+ * parameters (spatial_params=False), rows = M*Hy*Wy (NCHW order = symbol order)
+ * for per-element parameters (spatial_params=True, layers.py:127-129). */
 int dsic_cdf_tables_student(const float* sigma, const float* nu,
-                            const int* meta, uint16_t* tables, int B, int M,
+                            const int* meta, uint16_t* tables, int B, int rows,
                             int Lmax, int* err, void* stream);
 
 /* torchac.encode_float_cdf call sites :48,62: per image the z string then the
- * y string.  out: [B][cap_z + cap_y] bytes, ZERO-INITIALISED by the caller (bits
+ * y string.  per_element_y: tab_y has one row per y symbol ([B][M*HWy][Lmax])
+ * instead of one per channel.  out: [B][cap_z + cap_y] bytes, ZERO-INITIALISED by the caller (bits
  * are OR-ed in; z at offset 0, y at cap_z),
  * lengths [B][2] = {len_z, len_y}.  Symbol order C,H,W of the NCHW latents. */
 int dsic_range_encode(const float* y_nchw, const float* z_nchw, const int* meta,
                       const uint16_t* tab_y, const uint16_t* tab_z, int Lmax,
                       int B, int M, int HWy, int N, int HWz, uint8_t* out,
                       int64_t cap_y, int64_t cap_z, int* lengths, int* err,
-                      int streams_per_wg, void* stream);
+                      int streams_per_wg, int per_element_y, void* stream);
 
 /* torchac.decode_float_cdf call sites :96,116: string b starts at
  * in + b*stride and has lengths[b*lstride + loff] bytes; meta_off 0 = y, 2 = z.
@@ -246,7 +257,7 @@ int dsic_range_encode(const float* y_nchw, const float* z_nchw, const int* meta,
 int dsic_range_decode(const uint8_t* in, int64_t stride, const int* lengths,
                       int lstride, int loff, const int* meta, int meta_off,
                       const uint16_t* tables, int Lmax, int B, int C, int HW,
-                      float* out_nchw, int* err, void* stream);
+                      int per_element, float* out_nchw, int* err, void* stream);
 
 /* HIP stream limited to the CUs whose bit is set in mask_host[words] (bit i of
  * word i/32 = CU i).  Used to give the range coder its own few CUs beside the

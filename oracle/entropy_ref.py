@@ -112,8 +112,12 @@ def compress(y_q, z_q, sigma_y, nu_y, sigma_z, tail=10):
         tz = tables_gauss(sigma_z, zmin, zmax - zmin + 1)
         zs = range_encode(z_q[b].astype(np.int32) - zmin, tz, z_q.shape[2] * z_q.shape[3])
         ymin, ymax = support(y_q[b], tail)
-        ty = tables_student(sigma_y[b], nu_y[b], ymin, ymax - ymin + 1)
-        ys = range_encode(y_q[b].astype(np.int32) - ymin, ty, y_q.shape[2] * y_q.shape[3])
+        if np.ndim(sigma_y[b]) == 3:   # spatial_params: StudentT(df=nu_y[b], scale=sigma_y[b]) per element (:57)
+            ty = tables_student(np.ravel(sigma_y[b]), np.ravel(nu_y[b]), ymin, ymax - ymin + 1)
+            ys = range_encode(y_q[b].astype(np.int32) - ymin, ty, 1)
+        else:
+            ty = tables_student(sigma_y[b], nu_y[b], ymin, ymax - ymin + 1)
+            ys = range_encode(y_q[b].astype(np.int32) - ymin, ty, y_q.shape[2] * y_q.shape[3])
         strings.append([zs, ys])
         miny.append(ymin); maxy.append(ymax); minz.append(zmin); maxz.append(zmax)
     return {"strings": strings, "shape_y": list(y_q.shape), "shape_z": list(z_q.shape),
@@ -133,6 +137,7 @@ def decode_y(compressed, b, sigma_y, nu_y):
     """:108-117: y symbols of image b given its sigma/nu [M]."""
     _, M, Hy, Wy = compressed["shape_y"]
     ymin, ymax = compressed["min_y"][b], compressed["max_y"][b]
-    ty = tables_student(sigma_y, nu_y, ymin, ymax - ymin + 1)
-    s = range_decode(compressed["strings"][b][1], M * Hy * Wy, ty, Hy * Wy)
+    per_element = np.ndim(sigma_y) == 3
+    ty = tables_student(np.ravel(sigma_y), np.ravel(nu_y), ymin, ymax - ymin + 1)
+    s = range_decode(compressed["strings"][b][1], M * Hy * Wy, ty, 1 if per_element else Hy * Wy)
     return (s + ymin).astype(np.float32).reshape(M, Hy, Wy)

@@ -106,14 +106,21 @@ def hyper_analysis(sd, y, taps=None):
     return x
 
 
+def is_spatial(sd):
+    return "h_s.to_sigma.weight" in sd
+
+
 def hyper_synthesis(sd, z_hat, taps=None):
-    """layers.py:141-152, spatial_params=False: returns expanded log_sigma, log_nu."""
+    """layers.py:141-152: returns log_sigma, log_nu (expanded views for spatial_params=False,
+    the two 3x3 heads' outputs for spatial_params=True)."""
     t = F.relu(_convT(sd, "h_s.h_s.0", z_hat))
     if taps is not None:
         taps["h_s.0"] = t
     t = F.relu(_convT(sd, "h_s.h_s.2", t))
     if taps is not None:
         taps["h_s.2"] = t
+    if is_spatial(sd):   # layers.py:143-145
+        return _conv(sd, "h_s.to_sigma", t, 1), _conv(sd, "h_s.to_nu", t, 1)
     p = F.adaptive_avg_pool2d(t, 1)
     outs = []
     for head in ("mlp_sigma", "mlp_nu"):
@@ -160,9 +167,13 @@ def forward(sd, x, quant_mode="round", min_nu=2.0, max_nu=100.0, taps=None):
     y_tilde = quantize(y, quant_mode)
     z_tilde = quantize(z, quant_mode)
     log_sigma, log_nu = hyper_synthesis(sd, z_tilde, taps)
-    sigma = torch.exp(log_sigma).mean(dim=(2, 3), keepdim=True).expand_as(y_tilde)
-    nu = torch.clamp(torch.exp(log_nu).mean(dim=(2, 3), keepdim=True),
-                     min_nu, max_nu).expand_as(y_tilde)
+    if is_spatial(sd):   # model.py:49-51
+        sigma = torch.exp(log_sigma)
+        nu = torch.clamp(torch.exp(log_nu), min=min_nu, max=max_nu)
+    else:                # model.py:54-55
+        sigma = torch.exp(log_sigma).mean(dim=(2, 3), keepdim=True).expand_as(y_tilde)
+        nu = torch.clamp(torch.exp(log_nu).mean(dim=(2, 3), keepdim=True),
+                         min_nu, max_nu).expand_as(y_tilde)
     nll_y = student_t_bits(y_tilde, sigma, nu)
     nll_z = gaussian_bits(z_tilde, _t(sd, "z_prior.log_sigma"))
     y_hat = quantize(y, "round")

@@ -50,6 +50,13 @@ CASES = [
     ("b1_4ch_128x128_s1", 1, 4, 128, 128, 1, 30),
     ("b3_48x80_s3", 3, 3, 48, 80, 3, 40),
 ]
+# spatial_params=True (layers.py:127-129, model.py:49-51): per-element sigma/nu heads.  The
+# reference's own branch needs H and W to be multiples of 64 (h_s output = 4x the z grid
+# must equal the y grid; other sizes raise a shape error inside distributions.py:28).
+SPATIAL_CASES = [
+    ("spatial_b2_128x64_s1", 2, 3, 128, 64, 1, 50),
+    ("spatial_b1_192x192_s2", 1, 3, 192, 192, 2, 60),
+]
 
 N_SAMPLES = 64
 
@@ -59,22 +66,22 @@ def sample_idx(numel, tag):
     return np.minimum((u.astype(np.float64) * numel).astype(np.int64), numel - 1)
 
 
-def build_reference(in_ch, seed):
-    m = CompressionModel(N=128, M=192, spatial_params=False, min_nu=2,
+def build_reference(in_ch, seed, spatial=False):
+    m = CompressionModel(N=128, M=192, spatial_params=spatial, min_nu=2,
                          max_nu=100.0)
     if in_ch != 3:
         # config 5: same architecture, first/last layer re-sized
         m.g_a.g_a[0] = ref_layers.conv(in_ch, 128, 3, 1)
         m.g_s.g_s[12] = torch.nn.ConvTranspose2d(128, in_ch, 5, 2, 2,
                                                  output_padding=1)
-    sd = S.make_state_dict(seed=seed, in_ch=in_ch)
+    sd = S.make_state_dict(seed=seed, in_ch=in_ch, spatial_params=spatial)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()},
                       strict=True)
     return m.eval()
 
 
-def run_case(name, B, C, H, W, seed, first):
-    m = build_reference(C, seed)
+def run_case(name, B, C, H, W, seed, first, spatial=False):
+    m = build_reference(C, seed, spatial)
     x = torch.from_numpy(S.make_patches(first, B, H, W, C))
     acts = {}
     hooks = []
@@ -109,8 +116,9 @@ def run_case(name, B, C, H, W, seed, first):
         "sum_nll_z": out["nll_z"].double().sum(dim=(1, 2, 3)).numpy(),
         "R_clamped": np.array([R.item()], dtype=np.float64),
         "mse": np.array([D.item()], dtype=np.float64),
-        "sigma": out["sigma"][:, :, 0, 0].numpy().copy(),
-        "nu": out["nu"][:, :, 0, 0].numpy().copy(),
+        "sigma": (out["sigma"].numpy().copy() if spatial else out["sigma"][:, :, 0, 0].numpy().copy()),
+        "nu": (out["nu"].numpy().copy() if spatial else out["nu"][:, :, 0, 0].numpy().copy()),
+        "spatial": np.array([int(spatial)], dtype=np.int64),
         "y_tilde": out["y_tilde"].numpy().astype(np.int16),
         "z_tilde": out["z_tilde"].numpy().astype(np.int16),
         "x_hat_crop": out["x_hat"][:, :, :32, :32].numpy().copy(),
@@ -203,3 +211,5 @@ if __name__ == "__main__":
     run_units()
     for case in CASES:
         run_case(*case)
+    for case in SPATIAL_CASES:
+        run_case(*case, spatial=True)

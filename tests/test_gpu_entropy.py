@@ -163,8 +163,42 @@ def test_decoder_with_wide_supports(spread):
     ybytes = c["bytes"][:, c["cap_z"]:].contiguous()
     ylen = c["lengths"][:, 1].contiguous()
     _lib.check(_lib.load().dsic_range_decode(_p(ybytes), ybytes.shape[1], _p(ylen), 1, 0, _p(c["meta"]), 0,
-                                             _p(c["tab_y"]), 1000, B, M, Hy * Wy, _p(y_hat), _p(err), _stream()),
+                                             _p(c["tab_y"]), 1000, B, M, Hy * Wy, 0, _p(y_hat), _p(err), _stream()),
                "range_decode")
     assert int(err.item()) == 0
     assert torch.equal(y_hat.cpu(), torch.from_numpy(y))
     assert int(c["meta"][:, 1].max()) > (64 if spread >= 40 else 0)
+
+
+def test_spatial_params_model_and_entropy_path():
+    """spatial_params=True (layers.py:127-129, model.py:49-51): per-element sigma/nu, a table row per symbol."""
+    from dsic_amd import entropy
+    from dsic_amd.model import CompressionModel
+    from oracle import ref_model as O
+    sd = S.make_state_dict(seed=4, spatial_params=True)
+    m = CompressionModel(N=128, M=192, spatial_params=True, min_nu=2, max_nu=100.0)
+    assert not m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True).missing_keys
+    m = m.cuda().eval()
+    x = torch.from_numpy(S.make_patches(500, 2, 128, 64))
+    out = m(x.cuda(), quant_mode="round")
+    ref = O.forward(sd, x, "round")
+    assert out["sigma"].shape == ref["sigma"].shape == (2, 192, 8, 4)
+    np.testing.assert_allclose(out["sigma"].cpu().numpy(), ref["sigma"].numpy(), rtol=2e-4)
+    np.testing.assert_allclose(out["nu"].cpu().numpy(), ref["nu"].numpy(), rtol=2e-4)
+    bpp = out.sums.sum(dim=1).cpu().numpy() / (128 * 64)
+    bpp_ref = (ref["nll_y"].double().sum(dim=(1, 2, 3)) + ref["nll_z"].double().sum(dim=(1, 2, 3))).numpy() / (128 * 64)
+    assert np.max(np.abs(bpp - bpp_ref)) < 1e-4
+    ls, ln = m.h_s(out["z_tilde"])
+    rls, rln = O.hyper_synthesis(sd, ref["z_tilde"])
+    np.testing.assert_allclose(ls.cpu().numpy(), rls.numpy(), rtol=1e-4, atol=1e-5)
+    # entropy path on the GPU's own (y, z, sigma, nu): bytes identical to the oracle, exact round trip
+    y, z = out["y_tilde"].cpu().numpy(), out["z_tilde"].cpu().numpy()
+    sy, ny = out["sigma"].cpu().numpy(), out["nu"].cpu().numpy()
+    sz = torch.exp(m.z_prior.log_sigma).cpu().numpy()
+    want = E.compress(y, z, sy, ny, sz, tail=10)
+    got = entropy.custom_compress(m, x.cuda(), tail=10)
+    for b in range(2):
+        assert got["strings"][b][0] == want["strings"][b][0]
+        assert got["strings"][b][1] == want["strings"][b][1]
+        assert np.array_equal(E.decode_y(got, b, sy[b], ny[b]), y[b])
+    assert torch.equal(entropy.custom_decompress(m, got), out["x_hat"].clamp(0, 1))

@@ -18,10 +18,10 @@ TAP_ORDER = ([f"g_a.{2 * i}" for i in range(8)] + [f"h_a.{i}" for i in (0, 2, 4,
              + ["h_s.0", "h_s.2"] + [f"g_s.{2 * i}" for i in range(7)])
 
 
-def build_model(seed, in_ch):
+def build_model(seed, in_ch, spatial=False):
     from dsic_amd.model import CompressionModel
-    m = CompressionModel(N=128, M=192, spatial_params=False, min_nu=2, max_nu=100.0, in_ch=in_ch)
-    sd = S.make_state_dict(seed=seed, in_ch=in_ch)
+    m = CompressionModel(N=128, M=192, spatial_params=spatial, min_nu=2, max_nu=100.0, in_ch=in_ch)
+    sd = S.make_state_dict(seed=seed, in_ch=in_ch, spatial_params=spatial)
     missing = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     return m.cuda().eval(), sd
@@ -31,7 +31,8 @@ def build_model(seed, in_ch):
 def test_forward_matches_reference_fixture(path):
     g = np.load(path)
     B, C, H, W, seed, first = (int(v) for v in g["meta"])
-    m, _ = build_model(seed, C)
+    spatial = bool(g["spatial"][0]) if "spatial" in g.files else False
+    m, _ = build_model(seed, C, spatial)
     x = torch.from_numpy(S.make_patches(first, B, H, W, C)).cuda()
     out = m(x, quant_mode="round", collect_taps=True)
     assert set(out.keys()) == {"x_hat", "nll_y", "nll_z", "y", "y_tilde", "z", "z_tilde", "sigma", "nu"}
@@ -40,8 +41,13 @@ def test_forward_matches_reference_fixture(path):
     flips = int((yq != g["y_tilde"].astype(np.float32)).sum())
     zflips = int((zq != g["z_tilde"].astype(np.float32)).sum())
     assert flips <= 4 and zflips <= 1, (flips, zflips)
-    np.testing.assert_allclose(out["sigma"][:, :, 0, 0].cpu().numpy(), g["sigma"], rtol=1e-4)
-    np.testing.assert_allclose(out["nu"][:, :, 0, 0].cpu().numpy(), g["nu"], rtol=1e-4)
+    if spatial:   # per-element sigma/nu [B,M,H/16,W/16] (model.py:49-51)
+        assert out["sigma"].shape == out["y_tilde"].shape
+        np.testing.assert_allclose(out["sigma"].cpu().numpy(), g["sigma"], rtol=2e-4)
+        np.testing.assert_allclose(out["nu"].cpu().numpy(), g["nu"], rtol=2e-4)
+    else:
+        np.testing.assert_allclose(out["sigma"][:, :, 0, 0].cpu().numpy(), g["sigma"], rtol=1e-4)
+        np.testing.assert_allclose(out["nu"][:, :, 0, 0].cpu().numpy(), g["nu"], rtol=1e-4)
     sums = out.sums.cpu().numpy()
     bpp = sums.sum(axis=1) / (H * W)
     bpp_ref = (g["sum_nll_y"] + g["sum_nll_z"]) / (H * W)
@@ -95,9 +101,6 @@ def test_api_errors_and_modes():
     out = m(x, quant_mode="noise")
     d = (out["y_tilde"] - out["y"]).abs().max().item()
     assert 0.0 < d <= 0.5
-    with pytest.raises(NotImplementedError):
-        from dsic_amd.model import CompressionModel
-        CompressionModel(spatial_params=True)
     with pytest.raises(RuntimeError):
         m(x.cpu(), quant_mode="round")   # no CPU fallback
 

@@ -33,7 +33,7 @@ def test_argument_validation_without_gpu(L):
     # NULL pointers / bad shapes are rejected before anything touches the device
     assert L.dsic_conv2d_nhwc(None, None, None, None, None, None, 1, 8, 8, 8, 8, 3, 1, 0, None) == 1
     assert b"null" in L.dsic_last_error()
-    assert L.dsic_range_encode(None, None, None, None, None, 64, 1, 1, 1, 1, 1, None, 8, 8, None, None, 4, None) == 1
+    assert L.dsic_range_encode(None, None, None, None, None, 64, 1, 1, 1, 1, 1, None, 8, 8, None, None, 4, 0, None) == 1
     assert L.dsic_packed_conv_weight_floats(128, 3, 3) == 9 * 1 * 128 * 8
 
 

@@ -15,6 +15,7 @@ CASES = sorted(glob.glob(os.path.join(GOLDEN, "forward_*.npz")))
 
 
 def test_state_dict_spec_counts():
+    assert len(S.make_state_dict(spatial_params=True)) == 86
     sd = S.make_state_dict()
     assert len(sd) == 90
     assert sum(v.size for v in sd.values()) == 6483267
@@ -38,7 +39,8 @@ def test_forward_matches_reference(path):
     B, C, H, W, seed, first = (int(v) for v in g["meta"])
     if H * W * B > 128 * 128 * 2 and os.environ.get("DSIC_FAST_TESTS"):
         pytest.skip("fast mode")
-    sd = S.make_state_dict(seed=seed, in_ch=C)
+    spatial = bool(g["spatial"][0]) if "spatial" in g.files else False
+    sd = S.make_state_dict(seed=seed, in_ch=C, spatial_params=spatial)
     x = torch.from_numpy(S.make_patches(first, B, H, W, C))
     taps = {}
     out = O.forward(sd, x, "round", taps=taps)
@@ -49,8 +51,12 @@ def test_forward_matches_reference(path):
     flips = int((yq != g["y_tilde"].astype(np.float32)).sum())
     assert flips <= 4, flips
     assert int((out["z_tilde"].numpy() != g["z_tilde"].astype(np.float32)).sum()) <= 1
-    np.testing.assert_allclose(out["sigma"][:, :, 0, 0].numpy(), g["sigma"], rtol=2e-5)
-    np.testing.assert_allclose(out["nu"][:, :, 0, 0].numpy(), g["nu"], rtol=2e-5)
+    if spatial:   # per-element parameters (model.py:49-51)
+        np.testing.assert_allclose(out["sigma"].numpy(), g["sigma"], rtol=2e-5)
+        np.testing.assert_allclose(out["nu"].numpy(), g["nu"], rtol=2e-5)
+    else:
+        np.testing.assert_allclose(out["sigma"][:, :, 0, 0].numpy(), g["sigma"], rtol=2e-5)
+        np.testing.assert_allclose(out["nu"][:, :, 0, 0].numpy(), g["nu"], rtol=2e-5)
     sy = out["nll_y"].double().sum(dim=(1, 2, 3)).numpy()
     sz = out["nll_z"].double().sum(dim=(1, 2, 3)).numpy()
     bpp = (sy + sz) / (H * W)
