@@ -120,6 +120,41 @@ __global__ void reflect_pad_br_kernel(const float* __restrict__ src, float* __re
   dst[i] = src[(plane * H + sy) * W + sx];
 }
 
+// combinebandsall.py:7-12,35-36: per band  b -= min; b /= max (if max != 0); rgb = uint8(b*255).
+// One workgroup per (image, band) plane; out01 keeps the normalised float plane (the model
+// input), out_u8 (optional) the truncated 8-bit value the reference writes to PNG.
+__global__ __launch_bounds__(256) void normalize_bands_kernel(const float* __restrict__ src,
+                                                              float* __restrict__ out01,
+                                                              uint8_t* __restrict__ out_u8, int HW) {
+  __shared__ float red[2][4];
+  const float* p = src + (size_t)blockIdx.x * HW;
+  float mn = p[0], mx = p[0];
+  for (int i = threadIdx.x; i < HW; i += 256) {
+    const float v = p[i];
+    mn = fminf(mn, v);
+    mx = fmaxf(mx, v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_down(mn, o, 64));
+    mx = fmaxf(mx, __shfl_down(mx, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = mn;
+    red[1][threadIdx.x >> 6] = mx;
+  }
+  __syncthreads();
+  mn = fminf(fminf(red[0][0], red[0][1]), fminf(red[0][2], red[0][3]));
+  mx = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+  const float range = mx - mn;  // band.max() after the subtraction
+  for (int i = threadIdx.x; i < HW; i += 256) {
+    float v = p[i] - mn;
+    if (range != 0.f) v = v / range;
+    out01[(size_t)blockIdx.x * HW + i] = v;
+    if (out_u8) out_u8[(size_t)blockIdx.x * HW + i] = (uint8_t)(v * 255.f);
+  }
+}
+
 static int transpose_launch(const float* src, float* dst, int B, int R, int Cc, hipStream_t st) {
   dim3 grid(ceil_div(Cc, 32), ceil_div(R, 32), B), block(32, 8);
   hipLaunchKernelGGL(transpose_kernel, grid, block, 0, st, src, dst, R, Cc);
@@ -198,4 +233,12 @@ extern "C" int dsic_reflect_pad_br(const float* src, float* dst, int planes, int
   hipLaunchKernelGGL(reflect_pad_br_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, src, dst, H, W, Hp, Wp, total);
   return check_launch("reflect_pad");
+}
+
+extern "C" int dsic_normalize_bands(const float* bands, float* out01, uint8_t* out_u8, int planes, int HW,
+                                    void* stream) {
+  DSIC_REQUIRE(bands && out01 && planes > 0 && HW > 0, "normalize_bands: bad argument");
+  hipLaunchKernelGGL(normalize_bands_kernel, dim3(planes), dim3(256), 0, (hipStream_t)stream, bands, out01,
+                     out_u8, HW);
+  return check_launch("normalize_bands");
 }

@@ -14,6 +14,20 @@ from . import entropy, metrics
 from .model import rate_distortion_loss
 
 
+def combine_bands(bands, want_uint8=False):
+    """code/combinebandsall.py:7-12,35-36 on the GPU: bands [B,nb,H,W] raw reflectances (any float
+    scale, e.g. B04,B03,B02[,B08]) -> per-band min-max normalised float32 [B,nb,H,W] in [0,1]
+    (the model input) and, optionally, the uint8 image the reference saves."""
+    from . import lib as _lib
+    from .ops import _f32c, _p, _stream
+    b = _f32c(bands, "combine_bands")
+    B, nb, H, W = b.shape
+    out = torch.empty_like(b)
+    u8 = torch.empty((B, nb, H, W), dtype=torch.uint8, device=b.device) if want_uint8 else None
+    _lib.check(_lib.load().dsic_normalize_bands(_p(b), _p(out), _p(u8), B * nb, H * W, _stream()), "normalize_bands")
+    return (out, u8) if want_uint8 else out
+
+
 @torch.no_grad()
 def evaluate_batch(model, x, weights=(0.3, 0.5, 0.2)):
     """x: [B,C,h,w] in [0,1] on the GPU, any size >= 16.  Returns a list of per-image dicts with the

@@ -29,6 +29,7 @@ SIGNATURES = {
     "dsic_nhwc_to_nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "dsic_nchw_to_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "dsic_reflect_pad_br": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "dsic_normalize_bands": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "dsic_conv2d_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_int, c_int, _P]),
     "dsic_wino_weight_floats": (c_int64, [c_int, c_int]),

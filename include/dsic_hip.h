@@ -78,6 +78,12 @@ int dsic_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W,
 int dsic_reflect_pad_br(const float* src, float* dst, int planes, int H, int W,
                         int pad_h, int pad_w, void* stream);
 
+/* Band preparation of code/combinebandsall.py:7-12,35-36 for stacked Sentinel-2 bands:
+ * per plane b -= min(b); b /= max(b) (if non-zero).  bands/out01: [planes][HW] float32
+ * (planes = images x bands); out_u8 (may be NULL): uint8(b*255) as written to PNG. */
+int dsic_normalize_bands(const float* bands, float* out01, uint8_t* out_u8,
+                         int planes, int HW, void* stream);
+
 /* ---- convolutions (fp32 MFMA implicit GEMM, fused bias + activation) ----- */
 
 /* conv() + optional GDN/ReLU: nn.Conv2d(Cin,Cout,k,stride,padding=(k-1)/2)

@@ -119,3 +119,21 @@ def test_evaluate_image_like_the_entropy_script():
     assert torch.equal(r["x_hat"], out["x_hat"].clamp(0, 1))
     want = RM.ms_ssim(r["x_hat"].cpu(), x.cpu(), data_range=1.0).item()
     assert abs(r["ms_ssim5"] - want) < 1e-4
+
+
+def test_combine_bands_like_combinebandsall():
+    from dsic_amd import evaluate
+    rng = np.random.default_rng(3)
+    raw = (rng.random((2, 4, 40, 56)) * 3000 + 200).astype(np.float32)
+    raw[1, 2] = 777.0                                   # constant band: max == 0 after the shift
+    out, u8 = evaluate.combine_bands(torch.from_numpy(raw).cuda(), want_uint8=True)
+    want = raw.copy()
+    for b in range(2):
+        for c in range(4):
+            band = want[b, c]
+            band -= band.min()
+            if band.max() != 0:
+                band /= band.max()
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=0)
+    assert np.array_equal(u8.cpu().numpy(), (want * 255).astype(np.uint8))
+    assert float(out[1, 2].abs().max()) == 0.0
