@@ -43,6 +43,10 @@ struct WinoArgs {
   float* out;
   int B, H, W, Cin, Cout, CoutP;
   int act;
+  int nphase;  // 1, or 4: ConvTranspose2d(5,2,2,1) as four 3x3 sub-pixel phase convs sharing the input;
+               // work item w = spatial tile*4 + phase, U of phase p at u + p*u_phase_stride, output pixel
+               // (2*oy+py, 2*ox+px) of a [B,2H,2W,Cout] tensor
+  int64_t u_phase_stride;
   int s2d;  // store space-to-depth: [B,H/2,W/2,4*Cout] (feeds a 5x5/s2 layer run as 3x3 over 4*C)
   int tiles_x, tiles_y, ntiles;  // 16x8-pixel output tiles
 };
@@ -96,7 +100,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
   int ld_gy0 = 0, ld_gx0 = 0;
   bool ld_border = true;  // the 18x10 window of the aimed tile leaves the image somewhere
   const char* ld_base = (const char*)a.in;  // wave-uniform: image + chunk; lanes add a 32-bit byte offset
-  auto aim = [&](int tile, int chunk) {
+  auto aim = [&](int item, int chunk) {
+    const int tile = item / a.nphase;
     const int tx = tile % a.tiles_x;
     const int ty = (tile / a.tiles_x) % a.tiles_y;
     const int n = tile / (a.tiles_x * a.tiles_y);
@@ -165,7 +170,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
   floatx4 Bq[4];
 #pragma unroll
   for (int f = 0; f < 3; ++f)
-    Bq[f] = *(const floatx4*)((const char*)(a.u + (size_t)((ph * 8 + f) * Cin8) * wstep) + boff);
+    Bq[f] = *(const floatx4*)((const char*)(a.u + (size_t)((cur_tile < a.ntiles ? cur_tile : 0) % a.nphase) * a.u_phase_stride +
+                                           (size_t)((ph * 8 + f) * Cin8) * wstep) + boff);
   Bq[3] = Bq[0];
   while (cur_tile < a.ntiles) {
 #pragma unroll
@@ -173,6 +179,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
     const int next_tile = cur_tile + gridDim.x;
+    const float* u_cur = a.u + (size_t)(cur_tile % a.nphase) * a.u_phase_stride;
+    const float* u_nxt = a.u + (size_t)((next_tile < a.ntiles ? next_tile : cur_tile) % a.nphase) * a.u_phase_stride;
     tile_count++;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
       STAMP(chunk * 4 + 0);
@@ -184,8 +192,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
       // register ring three steps ahead (L2 latency), continuous across chunks and tiles
       // (U does not depend on the tile); V fragments one step ahead (LDS latency).
       const float* vb = lds + buf * WBUF + aread;
-      const float* ub = a.u + (size_t)(chunk * 4) * wstep;
-      const float* ubn = a.u + (size_t)((chunk + 1 == nchunks ? 0 : chunk + 1) * 4) * wstep;
+      const float* ub = u_cur + (size_t)(chunk * 4) * wstep;
+      const float* ubn = last ? u_nxt : u_cur + (size_t)((chunk + 1) * 4) * wstep;
       floatx4 Aq[2];
       Aq[0] = *(const floatx4*)(vb);
 #pragma unroll
@@ -260,9 +268,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
     STAMP(25);
 
     if (nvalid) {
-      const int tx = cur_tile % a.tiles_x;
-      const int ty = (cur_tile / a.tiles_x) % a.tiles_y;
-      const int n = cur_tile / (a.tiles_x * a.tiles_y);
+      const int stile = cur_tile / a.nphase, phase = cur_tile % a.nphase;
+      const int tx = stile % a.tiles_x;
+      const int ty = (stile / a.tiles_x) % a.tiles_y;
+      const int n = stile / (a.tiles_x * a.tiles_y);
+      const int up = a.nphase == 4 ? 2 : 1, ppy = phase >> 1, ppx = phase & 1;  // sub-pixel phase placement
       const int col = nt * 32 + l31;
       const bool cok = col < a.Cout;
       const float bias = cok ? a.bias[col] : 0.f;
@@ -291,7 +301,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
           const int oy = ty * 8 + 2 * (rr >> 3) + ph;
           const int ox = tx * 16 + 2 * (rr & 7) + j;
           if (oy < a.H && ox < a.W && nn < a.Cout) {
-            const size_t o = a.s2d ? (((size_t)n * (a.H >> 1) + (oy >> 1)) * (a.W >> 1) + (ox >> 1)) * (4 * a.Cout) +
+            const size_t o = up == 2 ? (((size_t)n * (2 * a.H) + (2 * oy + ppy)) * (2 * a.W) + (2 * ox + ppx)) * a.Cout + nn
+                             : a.s2d ? (((size_t)n * (a.H >> 1) + (oy >> 1)) * (a.W >> 1) + (ox >> 1)) * (4 * a.Cout) +
                                          ((oy & 1) * 2 + (ox & 1)) * a.Cout + nn
                                    : (((size_t)n * a.H + oy) * a.W + ox) * a.Cout + nn;
             *(floatx4*)(a.out + o) = v;
@@ -315,6 +326,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
 //         g_ab[u][v] = w[2u+a][2v+b] (zero where 2u+a or 2v+b exceeds 4): Cin = 4*Cs.
 __global__ void pack_wino_weight_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout,
                                         int Cin, int Cin8, int CoutP, int s2, int64_t total) {
+  // s2 = 2..5: phase (s2-2) = py*2+px of ConvTranspose2d(5,2,2,1), w [Cin][Cout][5][5]:
+  //   g[wr][wc] = w[c][n][py+4-2wr][px+4-2wc] for wr >= py, wc >= px, else 0
+  //   (output (2i+py, 2j+px) reads input (i-1+wr, j-1+wc); from oy = 2*iy - 2 + ky).
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int j = i & 7;
@@ -328,7 +342,15 @@ __global__ void pack_wino_weight_kernel(const float* __restrict__ w, float* __re
   float v = 0.f;
   if (n < Cout && c < Cin) {
     float g[9];
-    if (!s2) {
+    if (s2 >= 2) {
+      const int py = (s2 - 2) >> 1, px = (s2 - 2) & 1;
+      const float* gp = w + ((size_t)c * Cout + n) * 25;
+#pragma unroll
+      for (int wr = 0; wr < 3; ++wr)
+#pragma unroll
+        for (int wc = 0; wc < 3; ++wc)
+          g[wr * 3 + wc] = (wr >= py && wc >= px) ? gp[(py + 4 - 2 * wr) * 5 + (px + 4 - 2 * wc)] : 0.f;
+    } else if (!s2) {
       const float* gp = w + ((size_t)n * Cin + c) * 9;
 #pragma unroll
       for (int t = 0; t < 9; ++t) g[t] = gp[t];
@@ -390,6 +412,36 @@ extern "C" int dsic_pack_wino_s2_weight(const float* w_oihw5, float* dst, int Co
   return check_launch("pack_wino_s2_weight");
 }
 
+extern "C" int dsic_pack_wino_convT_weight(const float* w_iohw5, float* dst, int Cin, int Cout, void* stream) {
+  DSIC_REQUIRE(w_iohw5 && dst && Cout > 0 && Cin > 0 && Cin % 8 == 0, "pack_wino_convT_weight: bad argument");
+  const int Cin8 = Cin / 8, CoutP = round_up(Cout, 32);
+  const int64_t total = dsic_wino_weight_floats(Cout, Cin);
+  for (int phase = 0; phase < 4; ++phase) {
+    hipLaunchKernelGGL(pack_wino_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, w_iohw5, dst + (size_t)phase * total, Cout, Cin, Cin8, CoutP, 2 + phase,
+                       total);
+  }
+  return check_launch("pack_wino_convT_weight");
+}
+
+static int wino_launch(WinoArgs& a, hipStream_t st);
+
+extern "C" int dsic_conv_transpose2d_wino_nhwc(const float* in, const float* u_packed4, const float* bias,
+                                               const float* beta, const float* gamma, float* out, int B,
+                                               int H, int W, int Cin, int Cout, int act, void* stream) {
+  DSIC_REQUIRE(in && u_packed4 && bias && out, "convT_wino: null pointer");
+  DSIC_REQUIRE(B > 0 && H > 0 && W > 0, "convT_wino: empty tensor");
+  DSIC_REQUIRE(Cin > 0 && Cin % 32 == 0, "convT_wino: Cin=%d must be a positive multiple of 32", Cin);
+  DSIC_REQUIRE(Cout > 0 && Cout % 4 == 0 && Cout <= 128, "convT_wino: Cout=%d must be a multiple of 4, <= 128", Cout);
+  DSIC_REQUIRE(act >= 0 && act <= 3, "convT_wino: act=%d", act);
+  DSIC_REQUIRE(!(act == DSIC_ACT_GDN || act == DSIC_ACT_IGDN) || (beta && gamma), "convT_wino: IGDN needs beta and gamma");
+  WinoArgs a{};
+  a.in = in; a.u = u_packed4; a.bias = bias; a.beta = beta; a.gamma = gamma; a.out = out;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.CoutP = round_up(Cout, 32); a.act = act;
+  a.s2d = 0; a.nphase = 4; a.u_phase_stride = dsic_wino_weight_floats(Cout, Cin);
+  return wino_launch(a, (hipStream_t)stream);
+}
+
 extern "C" int dsic_conv3x3_wino_nhwc(const float* in, const float* u_packed, const float* bias,
                                       const float* beta, const float* gamma, float* out, int B, int H,
                                       int W, int Cin, int Cout, int act, int s2d_out, void* stream) {
@@ -404,8 +456,14 @@ extern "C" int dsic_conv3x3_wino_nhwc(const float* in, const float* u_packed, co
   DSIC_REQUIRE(!s2d_out || (H % 2 == 0 && W % 2 == 0), "conv3x3_wino: space-to-depth output needs even H and W");
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.CoutP = round_up(Cout, 32); a.act = act;
   a.s2d = s2d_out;
+  a.nphase = 1; a.u_phase_stride = 0;
+  return wino_launch(a, (hipStream_t)stream);
+}
+
+static int wino_launch(WinoArgs& a, hipStream_t st) {
+  const int B = a.B, H = a.H, W = a.W;
   a.tiles_x = ceil_div(W, 16); a.tiles_y = ceil_div(H, 8);
-  const int64_t nt = (int64_t)a.tiles_x * a.tiles_y * B;
+  const int64_t nt = (int64_t)a.tiles_x * a.tiles_y * B * a.nphase;
   DSIC_REQUIRE(nt < ((int64_t)1 << 31), "conv3x3_wino: too many tiles");
   a.ntiles = (int)nt;
   static bool attr_set = false;
@@ -427,6 +485,6 @@ extern "C" int dsic_conv3x3_wino_nhwc(const float* in, const float* u_packed, co
     if (max_grid < 1 || max_grid > 1024) max_grid = 256;
   }
   const int grid = a.ntiles < max_grid ? a.ntiles : max_grid;
-  hipLaunchKernelGGL(conv_wino_kernel, dim3(grid), dim3(512), WLDS_BYTES, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(conv_wino_kernel, dim3(grid), dim3(512), WLDS_BYTES, st, a);
   return check_launch("conv3x3_wino");
 }

@@ -172,9 +172,16 @@ class ConvTranspose2d(_ConvBase):
     def to_image(self):
         return self.out_channels % 8 != 0
 
+    @property
+    def use_winograd(self):
+        return (USE_WINOGRAD and not self.to_image and self.in_channels % 32 == 0
+                and self.out_channels % 4 == 0 and 64 <= self.out_channels <= 128)
+
     def _pack(self):
         if self.to_image:
             return ops.pack_convT_image_weight(self.weight)
+        if self.use_winograd:
+            return ops.pack_wino_convT_weight(self.weight)
         return ops.pack_convT_weight(self.weight)
 
     def run_nhwc(self, x, act=ops.ACT_NONE, gdn=None):
@@ -183,6 +190,8 @@ class ConvTranspose2d(_ConvBase):
         beta = gamma = None
         if gdn is not None:
             beta, gamma = gdn.effective()
+        if self.use_winograd:
+            return ops.conv_transpose2d_wino_nhwc(x, self.packed(), self.bias, self.out_channels, act, beta, gamma)
         return ops.conv_transpose2d_nhwc(x, self.packed(), self.bias, self.out_channels, act, beta, gamma)
 
     @torch.no_grad()

@@ -167,6 +167,34 @@ def pack_wino_s2_weight(w: torch.Tensor) -> torch.Tensor:
     return dst
 
 
+def pack_wino_convT_weight(w: torch.Tensor) -> torch.Tensor:
+    """ConvTranspose2d weight [Cin,Cout,5,5] -> Winograd U of its four 3x3 sub-pixel phase convs."""
+    w = _f32c(w, "pack_wino_convT_weight")
+    Cin, Cout, k, k2 = w.shape
+    if (k, k2) != (5, 5):
+        raise ValueError("pack_wino_convT_weight: kernel must be 5x5")
+    L = _lib.load()
+    dst = torch.empty(4 * L.dsic_wino_weight_floats(Cout, Cin), dtype=torch.float32, device=w.device)
+    _lib.check(L.dsic_pack_wino_convT_weight(_p(w), _p(dst), Cin, Cout, _stream()), "pack_wino_convT_weight")
+    return dst
+
+
+def conv_transpose2d_wino_nhwc(x, u_packed4, bias, Cout, act=ACT_NONE, beta=None, gamma=None, out=None):
+    """ConvTranspose2d(Cin,Cout,5,2,2,1) + fused activation: four Winograd 3x3 phase convs."""
+    x = _f32c(x, "conv_transpose2d_wino_nhwc")
+    B, H, W, Cin = x.shape
+    if out is None:
+        out = torch.empty((B, 2 * H, 2 * W, Cout), dtype=torch.float32, device=x.device)
+    L = _lib.load()
+    wino_tiles = 4 * B * (-(-H // 8)) * (-(-W // 16)) * 32
+    _timed("conv_wino_kernel", 2.0 * B * H * W * Cout * Cin * 25,
+           lambda: _lib.check(L.dsic_conv_transpose2d_wino_nhwc(_p(x), _p(u_packed4), _p(bias), _p(beta), _p(gamma),
+                                                                _p(out), B, H, W, Cin, Cout, act, _stream()),
+                              "conv_transpose2d_wino_nhwc"),
+           exec_flops=2.0 * wino_tiles * 16 * Cin * round_up(Cout, 32))
+    return out
+
+
 def space_to_depth(x_nhwc):
     """[B,H,W,C] -> [B,H/2,W/2,4C] with channel (a*2+b)*C+c = x[2i+a][2j+b][c] (layout plumbing)."""
     B, H, W, C = x_nhwc.shape

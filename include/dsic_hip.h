@@ -116,6 +116,19 @@ int dsic_conv3x3_wino_nhwc(const float* in, const float* u_packed,
  * Cin = 4*Cs on the half-resolution grid. */
 int dsic_pack_wino_s2_weight(const float* w_oihw5, float* dst, int Cout, int Cs,
                              void* stream);
+/* ConvTranspose2d(Cin,Cout,5,2,2,output_padding=1) + optional IGDN/ReLU
+ * (layers.py:83,89,93,123,124) by Winograd: each sub-pixel phase (py,px) is a 3x3
+ * stride-1 conv over the input grid with taps g[wr][wc] = w[py+4-2wr][px+4-2wc]
+ * (zero for wr < py or wc < px), so all four share the transformed input.  dst/u_packed4:
+ * 4 * dsic_wino_weight_floats(Cout, Cin) floats.  in NHWC [B,H,W,Cin] -> out NHWC
+ * [B,2H,2W,Cout].  Cin % 32 == 0, Cout % 4 == 0, Cout <= 128. */
+int dsic_pack_wino_convT_weight(const float* w_iohw5, float* dst, int Cin,
+                                int Cout, void* stream);
+int dsic_conv_transpose2d_wino_nhwc(const float* in, const float* u_packed4,
+                                    const float* bias, const float* beta,
+                                    const float* gamma, float* out, int B,
+                                    int H, int W, int Cin, int Cout, int act,
+                                    void* stream);
 
 /* First analysis layer conv(Cimg,Cout,3,1) + optional GDN/ReLU (layers.py:51)
  * read straight from the NCHW image [B,Cimg,H,W] (Cimg 3 or 4) with K = 9*Cimg;

@@ -262,3 +262,26 @@ def test_space_to_depth_epilogues(ops):
     w2 = ops.pack_wino_weight(_rand((128, 128, 3, 3), 64, 0.05).cuda())
     y = ops.conv3x3_wino_nhwc(a, w2, b, 128)
     assert torch.equal(ops.conv3x3_wino_nhwc(a, w2, b, 128, s2d_out=True), ops.space_to_depth(y))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,act", [(2, 192, 128, 5, 7, "igdn"), (1, 128, 128, 16, 24, "igdn"),
+                                                (1, 128, 128, 9, 17, "relu"), (9, 128, 128, 2, 3, "none"),
+                                                (2, 128, 64, 32, 16, "none")])
+def test_conv_transpose_winograd_vs_oracle(ops, B, Cin, Cout, H, W, act):
+    x = _rand((B, Cin, H, W), 71, 2.0)
+    w = _rand((Cin, Cout, 5, 5), 72, (Cin * 6.25) ** -0.5 * 2)
+    b = _rand((Cout,), 73, 0.5)
+    beta_p = torch.sqrt(0.5 + torch.rand(Cout, generator=torch.Generator().manual_seed(4)) + 2 ** -18)
+    gam_p = torch.sqrt(0.02 + 0.28 * torch.rand(Cout, generator=torch.Generator().manual_seed(5)) + 2 ** -18)
+    ref = O._convT({"p.weight": w, "p.bias": b}, "p", x)
+    code = {"none": ops.ACT_NONE, "igdn": ops.ACT_IGDN, "relu": ops.ACT_RELU}[act]
+    if act == "igdn":
+        ref = O.gdn(ref, beta_p, gam_p.view(-1, 1, 1, 1), True)
+    elif act == "relu":
+        ref = torch.relu(ref)
+    y = ops.conv_transpose2d_wino_nhwc(_nhwc(x).cuda(), ops.pack_wino_convT_weight(w.cuda()), b.cuda(), Cout, code,
+                                       (beta_p ** 2 - 2 ** -18).cuda(), (gam_p ** 2 - 2 ** -18).cuda())
+    got = ops.nhwc_to_nchw(y).cpu()
+    assert got.shape == ref.shape
+    err = float((got - ref).abs().max())
+    assert err <= _tol(ref, Cin * 9) * 6, (err, float(ref.abs().max()))
