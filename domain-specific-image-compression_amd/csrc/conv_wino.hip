@@ -47,6 +47,7 @@ struct WinoArgs {
                // work item w = spatial tile*4 + phase, U of phase p at u + p*u_phase_stride, output pixel
                // (2*oy+py, 2*ox+px) of a [B,2H,2W,Cout] tensor
   int64_t u_phase_stride;
+  int s2d_in;  // input is the space-to-depth image of a 5x5/s2 layer: Cin = 4*Cs, channel block (a,b)
   int s2d;  // store space-to-depth: [B,H/2,W/2,4*Cout] (feeds a 5x5/s2 layer run as 3x3 over 4*C)
   int tiles_x, tiles_y, ntiles;  // 16x8-pixel output tiles
 };
@@ -72,6 +73,10 @@ constexpr int WP = WCK + 4;                // LDS floats per (pos, tile) row
 constexpr int WBUF = 16 * 32 * WP;         // floats per V buffer
 constexpr int WLDS_BYTES = 2 * WBUF * 4;   // 147456
 
+// ZSKIP: the launch has structurally zero Winograd positions (space-to-depth input or
+// ConvTranspose2d phases) whose MFMA clusters are skipped; plain 3x3 layers use ZSKIP = false
+// and carry no test in the loop.
+template <bool ZSKIP>
 __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -191,6 +196,29 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
       // consumer: 8 positions x 4 sub-chunks x 4 k-steps.  U fragments run in a 4-deep
       // register ring three steps ahead (L2 latency), continuous across chunks and tiles
       // (U does not depend on the tile); V fragments one step ahead (LDS latency).
+      // Structurally zero Winograd positions: a 3-tap filter with a zero end tap has a zero
+      // transform component (G (g0,g1,0)^T)[3] = 0, (G (0,g1,g2)^T)[0] = 0.  For the space-to-depth
+      // form of a 5x5/s2 kernel the phases a=1 / b=1 lack the last row / column (xi=3 / nu=3
+      // vanish); for a ConvTranspose2d phase py=1 / px=1 lacks the first row / column (xi=0 /
+      // nu=0 vanish).  Those MFMA clusters are skipped: 49 instead of 64 position-phase GEMMs.
+      unsigned zero_xi = 4, zero_nu = 4, zero_xi_n = 4, zero_nu_n = 4;  // this chunk / the next one; 4 = none
+      if (ZSKIP && a.s2d_in) {
+        const int per = nchunks >> 2;
+        const int blk = chunk / per;  // channel block (a,b) = (blk>>1, blk&1)
+        const int blk_n = last ? 0 : (chunk + 1) / per;
+        if (blk >> 1) zero_xi = 3;
+        if (blk & 1) zero_nu = 3;
+        if (blk_n >> 1) zero_xi_n = 3;
+        if (blk_n & 1) zero_nu_n = 3;
+      } else if (ZSKIP && a.nphase == 4) {
+        const int phase = cur_tile & 3;  // grid is a multiple of 4: the next item has the same phase
+        if (phase >> 1) zero_xi = zero_xi_n = 0;
+        if (phase & 1) zero_nu = zero_nu_n = 0;
+      }
+      auto is_zero = [&](int f) {  // step f of this chunk (f < 32) or f-32 of the next
+        const unsigned xi = (unsigned)(ph * 2 + ((f & 7) >> 2)), nu = (unsigned)(f & 3);
+        return f < 32 ? (xi == zero_xi || nu == zero_nu) : (xi == zero_xi_n || nu == zero_nu_n);
+      };
       const float* vb = lds + buf * WBUF + aread;
       const float* ub = u_cur + (size_t)(chunk * 4) * wstep;
       const float* ubn = last ? u_nxt : u_cur + (size_t)((chunk + 1) * 4) * wstep;
@@ -210,11 +238,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
           Aq[(it + 1) & 1] = *(const floatx4*)(vb + p1 * 32 * WP + s1 * 8);
         }
         const int p0 = it & 7;
-        __builtin_amdgcn_s_setprio(1);
+        if (!ZSKIP || !is_zero(it)) {  // wave-uniform
+          __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-          acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aq[it & 1][s], Bq[it & 3][s], acc[p0], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+          for (int s = 0; s < 4; ++s)
+            acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aq[it & 1][s], Bq[it & 3][s], acc[p0], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
+        }
         if (it >= 20 && it < 28 && have_next) transform_piece(it - 20, lds + (buf ^ 1) * WBUF);
       }
       STAMP(chunk * 4 + 1);
@@ -438,13 +468,14 @@ extern "C" int dsic_conv_transpose2d_wino_nhwc(const float* in, const float* u_p
   WinoArgs a{};
   a.in = in; a.u = u_packed4; a.bias = bias; a.beta = beta; a.gamma = gamma; a.out = out;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.CoutP = round_up(Cout, 32); a.act = act;
-  a.s2d = 0; a.nphase = 4; a.u_phase_stride = dsic_wino_weight_floats(Cout, Cin);
+  a.s2d = 0; a.s2d_in = 0; a.nphase = 4; a.u_phase_stride = dsic_wino_weight_floats(Cout, Cin);
   return wino_launch(a, (hipStream_t)stream);
 }
 
 extern "C" int dsic_conv3x3_wino_nhwc(const float* in, const float* u_packed, const float* bias,
                                       const float* beta, const float* gamma, float* out, int B, int H,
-                                      int W, int Cin, int Cout, int act, int s2d_out, void* stream) {
+                                      int W, int Cin, int Cout, int act, int s2d_out, int s2d_in,
+                                      void* stream) {
   DSIC_REQUIRE(in && u_packed && bias && out, "conv3x3_wino: null pointer");
   DSIC_REQUIRE(B > 0 && H > 0 && W > 0, "conv3x3_wino: empty tensor");
   DSIC_REQUIRE(Cin > 0 && Cin % 32 == 0, "conv3x3_wino: Cin=%d must be a positive multiple of 32", Cin);
@@ -456,6 +487,8 @@ extern "C" int dsic_conv3x3_wino_nhwc(const float* in, const float* u_packed, co
   DSIC_REQUIRE(!s2d_out || (H % 2 == 0 && W % 2 == 0), "conv3x3_wino: space-to-depth output needs even H and W");
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.CoutP = round_up(Cout, 32); a.act = act;
   a.s2d = s2d_out;
+  DSIC_REQUIRE(!s2d_in || Cin % 128 == 0, "conv3x3_wino: space-to-depth input needs Cin = 4*Cs with Cs %% 32 == 0");
+  a.s2d_in = s2d_in ? 1 : 0;
   a.nphase = 1; a.u_phase_stride = 0;
   return wino_launch(a, (hipStream_t)stream);
 }
@@ -468,8 +501,11 @@ static int wino_launch(WinoArgs& a, hipStream_t st) {
   a.ntiles = (int)nt;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       WLDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wino_kernel<false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, WLDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)conv_wino_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              WLDS_BYTES);
     if (e != hipSuccess) {
       set_error("conv3x3_wino: hipFuncSetAttribute: %s", hipGetErrorString(e));
       return DSIC_EHIP;
@@ -485,6 +521,9 @@ static int wino_launch(WinoArgs& a, hipStream_t st) {
     if (max_grid < 1 || max_grid > 1024) max_grid = 256;
   }
   const int grid = a.ntiles < max_grid ? a.ntiles : max_grid;
-  hipLaunchKernelGGL(conv_wino_kernel, dim3(grid), dim3(512), WLDS_BYTES, st, a);
+  if (a.s2d_in || a.nphase == 4)
+    hipLaunchKernelGGL(conv_wino_kernel<true>, dim3(grid), dim3(512), WLDS_BYTES, st, a);
+  else
+    hipLaunchKernelGGL(conv_wino_kernel<false>, dim3(grid), dim3(512), WLDS_BYTES, st, a);
   return check_launch("conv3x3_wino");
 }

@@ -132,7 +132,7 @@ class Conv2d(_ConvBase):
         if x_is_s2d:
             B, H2, W2, _ = x.shape
             return ops.conv3x3_wino_nhwc(x, self.packed_wino(), self.bias, self.out_channels, act, beta, gamma,
-                                         s2d_out=s2d_out,
+                                         s2d_out=s2d_out, s2d_in=True,
                                          algo_flops=2.0 * B * H2 * W2 * self.out_channels * self.in_channels * 25)
         if self.use_winograd and x.shape[-1] == self.in_channels:
             return ops.conv3x3_wino_nhwc(x, self.packed_wino(), self.bias, self.out_channels, act, beta, gamma,

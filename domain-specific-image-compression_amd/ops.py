@@ -187,11 +187,11 @@ def conv_transpose2d_wino_nhwc(x, u_packed4, bias, Cout, act=ACT_NONE, beta=None
         out = torch.empty((B, 2 * H, 2 * W, Cout), dtype=torch.float32, device=x.device)
     L = _lib.load()
     wino_tiles = 4 * B * (-(-H // 8)) * (-(-W // 16)) * 32
-    _timed("conv_wino_kernel", 2.0 * B * H * W * Cout * Cin * 25,
+    _timed("conv_wino_kernel<1>", 2.0 * B * H * W * Cout * Cin * 25,
            lambda: _lib.check(L.dsic_conv_transpose2d_wino_nhwc(_p(x), _p(u_packed4), _p(bias), _p(beta), _p(gamma),
                                                                 _p(out), B, H, W, Cin, Cout, act, _stream()),
                               "conv_transpose2d_wino_nhwc"),
-           exec_flops=2.0 * wino_tiles * 16 * Cin * round_up(Cout, 32))
+           exec_flops=2.0 * wino_tiles * 12.25 * Cin * round_up(Cout, 32))
     return out
 
 
@@ -208,7 +208,7 @@ def depth_to_space(x_s2d):
 
 
 def conv3x3_wino_nhwc(x, u_packed, bias, Cout, act=ACT_NONE, beta=None, gamma=None, out=None, s2d_out=False,
-                      algo_flops=None):
+                      algo_flops=None, s2d_in=False):
     """conv(Cin,Cout,3,1) + fused activation by Winograd F(2x2,3x3) on NHWC activations.
 
     s2d_out: write [B,H/2,W/2,4*Cout] (space-to-depth) for a following 5x5/s2 layer."""
@@ -219,11 +219,13 @@ def conv3x3_wino_nhwc(x, u_packed, bias, Cout, act=ACT_NONE, beta=None, gamma=No
         out = torch.empty(shape, dtype=torch.float32, device=x.device)
     L = _lib.load()
     wino_tiles = B * (-(-H // 8)) * (-(-W // 16)) * 32          # 2x2-output tiles incl. border padding
-    _timed("conv_wino_kernel", algo_flops if algo_flops is not None else 2.0 * B * H * W * Cout * Cin * 9,
+    _timed("conv_wino_kernel<1>" if s2d_in else "conv_wino_kernel<0>",
+           algo_flops if algo_flops is not None else 2.0 * B * H * W * Cout * Cin * 9,
            lambda: _lib.check(L.dsic_conv3x3_wino_nhwc(_p(x), _p(u_packed), _p(bias), _p(beta), _p(gamma), _p(out),
-                                                       B, H, W, Cin, Cout, act, int(bool(s2d_out)), _stream()),
+                                                       B, H, W, Cin, Cout, act, int(bool(s2d_out)), int(bool(s2d_in)),
+                                                       _stream()),
                               "conv3x3_wino_nhwc"),
-           exec_flops=2.0 * wino_tiles * 16 * Cin * round_up(Cout, 32))
+           exec_flops=2.0 * wino_tiles * (12.25 if s2d_in else 16) * Cin * round_up(Cout, 32))
     return out
 
 

@@ -107,13 +107,15 @@ int dsic_pack_wino_weight(const float* w_oihw, float* dst, int Cout, int Cin,
 int dsic_conv3x3_wino_nhwc(const float* in, const float* u_packed,
                            const float* bias, const float* beta,
                            const float* gamma, float* out, int B, int H, int W,
-                           int Cin, int Cout, int act, int s2d_out, void* stream);
+                           int Cin, int Cout, int act, int s2d_out, int s2d_in,
+                           void* stream);
 /* conv(Cs,Cout,5,2) (layers.py:54,60,65) as a 3x3 stride-1 Winograd conv over the
  * space-to-depth input [B,H/2,W/2,4*Cs] (channel (a*2+b)*Cs+c = x[2i+a][2j+b][c],
  * written by the producing layer when its s2d_out flag is set): 16 instead of
  * 25 multiplies per output and channel pair.  Pack the reference [Cout,Cs,5,5]
  * weight with dsic_pack_wino_s2_weight and call dsic_conv3x3_wino_nhwc with
- * Cin = 4*Cs on the half-resolution grid. */
+ * Cin = 4*Cs on the half-resolution grid and s2d_in = 1 (lets the kernel skip the
+ * Winograd positions that are structurally zero for the phases lacking a tap row/column). */
 int dsic_pack_wino_s2_weight(const float* w_oihw5, float* dst, int Cout, int Cs,
                              void* stream);
 /* ConvTranspose2d(Cin,Cout,5,2,2,output_padding=1) + optional IGDN/ReLU

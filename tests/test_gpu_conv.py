@@ -244,7 +244,7 @@ def test_conv5x5_stride2_as_winograd_over_space_to_depth(ops, B, Cs, Cout, H, W,
         ref = torch.relu(ref)
     xs = ops.space_to_depth(_nhwc(x).cuda())
     y = ops.conv3x3_wino_nhwc(xs, ops.pack_wino_s2_weight(w.cuda()), b.cuda(), Cout, code,
-                              (beta_p ** 2 - 2 ** -18).cuda(), (gam_p ** 2 - 2 ** -18).cuda())
+                              (beta_p ** 2 - 2 ** -18).cuda(), (gam_p ** 2 - 2 ** -18).cuda(), s2d_in=True)
     got = ops.nhwc_to_nchw(y).cpu()
     assert got.shape == ref.shape
     err = float((got - ref).abs().max())

@@ -37,7 +37,7 @@ for name, kind, ci, co, h, k, s in LAYERS:
     elif kind == "conv" and k == 5 and co <= 128 and os.environ.get("DSIC_WINOGRAD", "1") != "0":
         xs = torch.randn(B, h // 2, h // 2, 4 * ci, device="cuda")
         w = ops.pack_wino_s2_weight(torch.randn(co, ci, 5, 5, device="cuda") * 0.05)
-        f = lambda: ops.conv3x3_wino_nhwc(xs, w, bias, co, ops.ACT_GDN, beta, gamma)
+        f = lambda: ops.conv3x3_wino_nhwc(xs, w, bias, co, ops.ACT_GDN, beta, gamma, s2d_in=True)
         flops = 2.0 * B * (h // 2) ** 2 * co * ci * 25
     elif kind == "conv" and k == 3 and os.environ.get("DSIC_WINOGRAD", "1") != "0":
         w = ops.pack_wino_weight(torch.randn(co, ci, 3, 3, device="cuda") * 0.05)

@@ -28,6 +28,10 @@ def short(name):
         args = [a.strip() for a in m.group(1).split(",")]
         args = ["1" if a == "true" else "0" if a == "false" else a for a in args]
         return "conv_igemm_kernel<" + ",".join(args) + ">"
+    m = re.search(r"(conv_wino_kernel|conv_first_kernel)<([^>]*)>", name)
+    if m:
+        arg = {"true": "1", "false": "0"}.get(m.group(2).strip(), m.group(2).strip())
+        return f"{m.group(1)}<{arg}>"
     return re.sub(r"\(.*", "", name).replace("void ", "").replace("dsic::", "")
 
 
