@@ -252,7 +252,7 @@ def main():
                 "value_1thread": v_one,
             }
         print(json.dumps(res))
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -19,15 +19,33 @@ def env_rank_world():
 
 
 def init(backend: str, device=None):
-    """init_process_group from the torchrun environment; no-op for world size 1."""
-    _, _, world = env_rank_world()
-    if world == 1:
+    """init_process_group from the torchrun environment (RANK/WORLD_SIZE/MASTER_* set by
+    torch.distributed.run); no-op for a plain `python bench.py`."""
+    if "RANK" not in os.environ or "WORLD_SIZE" not in os.environ:
         return False
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     kw = {}
     if backend == "nccl" and device is not None:
         kw["device_id"] = device
-    dist.init_process_group(backend, **kw)
+    if backend != "nccl" or device is None:
+        dist.init_process_group(backend, **kw)
+        return True
+    # RCCL prints a banner ("Hostname", "Librccl path") on STDOUT while the communicator is
+    # created (eagerly with device_id, or at the first collective): do both with fd 1 pointed at
+    # stderr so that a caller's stdout stays clean (bench.py must print exactly one JSON line).
+    import sys
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        dist.init_process_group(backend, **kw)
+        t = torch.zeros(1, device=device)
+        dist.all_reduce(t)
+        torch.cuda.synchronize(device)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
     return True
 
 
@@ -38,13 +56,13 @@ def shard_first_index(rank: int, per_rank: int) -> int:
 
 def reduce_metric_sums(t: torch.Tensor) -> torch.Tensor:
     """In-place all-reduce(sum) of the per-rank metric sums (fp64 vector)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
 
 def max_over_ranks(value: float, device) -> float:
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         t = torch.tensor([value], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
@@ -52,5 +70,5 @@ def max_over_ranks(value: float, device) -> float:
 
 
 def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()
