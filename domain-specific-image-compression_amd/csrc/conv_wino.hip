@@ -76,6 +76,10 @@ constexpr int WLDS_BYTES = 2 * WBUF * 4;   // 147456
 // ZSKIP: the launch has structurally zero Winograd positions (space-to-depth input or
 // ConvTranspose2d phases) whose MFMA clusters are skipped; plain 3x3 layers use ZSKIP = false
 // and carry no test in the loop.
+// Register budget: the kernel must stay at <= 240 VGPRs.  Two of these waves per SIMD then leave 32
+// of the 512-entry file, so a small wave of another stream (the serial range coder, 24 VGPRs) can
+// stay resident beside this persistent kernel instead of waiting for a CU to drain.  Hence the U
+// ring is only two deep (a deeper ring measured no faster).
 template <bool ZSKIP>
 __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -124,35 +128,40 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
   };
   // ---- producer: B^T d B for this thread's two xi rows, in 8 pieces that are issued between
   // MFMA clusters (VALU and LDS writes ride in the shadow of the 64-cycle MFMAs) ---------------
-  floatx4 tr[2][4];
+  // Columns first, in place (d B needs one window row at a time and overwrites it), rows second
+  // with the results stored straight to LDS: no intermediate tile, 32 fewer live registers.
+  //   pieces 0..2: local row i:  (w0,w1,w2,w3) = (d0-d2, d1+d2, d2-d1, d1-d3), out-of-image zeroed
+  //   pieces 3..6: xi row x = (piece-3)>>1, nu pair (piece-3)&1:  xi0 = r0-r2, xi1 = r1+r2  (pr=0)
+  //                                                               xi2 = r1-r0, xi3 = r0-r2  (pr=1, rows d1,d2,d3)
   auto transform_piece = [&](int piece, float* vbuf) {
-    if (piece < 4) {  // row combination of window column j = piece
-      const int j = piece;
-      floatx4 r0 = raw[0 * 4 + j], r1 = raw[1 * 4 + j], r2 = raw[2 * 4 + j];
+    if (piece < 3) {
+      const int i = piece;
+      floatx4 d0 = raw[i * 4 + 0], d1 = raw[i * 4 + 1], d2 = raw[i * 4 + 2], d3 = raw[i * 4 + 3];
       if (ld_border) {
-        const int gx = ld_gx0 + j;
-        const bool xok = gx >= 0 && gx < a.W;
+        const int gy = ld_gy0 + i;
+        const bool yok = gy >= 0 && gy < a.H;
         const floatx4 z = {0.f, 0.f, 0.f, 0.f};
-        if (!(xok && ld_gy0 >= 0 && ld_gy0 < a.H)) r0 = z;
-        if (!(xok && ld_gy0 + 1 >= 0 && ld_gy0 + 1 < a.H)) r1 = z;
-        if (!(xok && ld_gy0 + 2 >= 0 && ld_gy0 + 2 < a.H)) r2 = z;
+        if (!(yok && ld_gx0 >= 0 && ld_gx0 < a.W)) d0 = z;
+        if (!(yok && ld_gx0 + 1 >= 0 && ld_gx0 + 1 < a.W)) d1 = z;
+        if (!(yok && ld_gx0 + 2 >= 0 && ld_gx0 + 2 < a.W)) d2 = z;
+        if (!(yok && ld_gx0 + 3 >= 0 && ld_gx0 + 3 < a.W)) d3 = z;
       }
-      if (pr == 0) {
-        tr[0][j] = r0 - r2;  // xi0 = d0 - d2
-        tr[1][j] = r1 + r2;  // xi1 = d1 + d2
-      } else {               // local rows are d1,d2,d3
-        tr[0][j] = r1 - r0;  // xi2 = d2 - d1
-        tr[1][j] = r0 - r2;  // xi3 = d1 - d3
-      }
-    } else {  // column combination: pieces 4,5 -> x=0 (nu 0,1 / 2,3); 6,7 -> x=1
-      const int x = (piece - 4) >> 1, half = (piece - 4) & 1;
-      float* dst = vbuf + vwrite + (x * 4) * 32 * WP;
-      if (half == 0) {
-        *(floatx4*)(dst + 0 * 32 * WP) = tr[x][0] - tr[x][2];
-        *(floatx4*)(dst + 1 * 32 * WP) = tr[x][1] + tr[x][2];
-      } else {
-        *(floatx4*)(dst + 2 * 32 * WP) = tr[x][2] - tr[x][1];
-        *(floatx4*)(dst + 3 * 32 * WP) = tr[x][1] - tr[x][3];
+      raw[i * 4 + 0] = d0 - d2;
+      raw[i * 4 + 1] = d1 + d2;
+      raw[i * 4 + 2] = d2 - d1;
+      raw[i * 4 + 3] = d1 - d3;
+    } else {
+      const int x = (piece - 3) >> 1, half = (piece - 3) & 1;
+      float* dst = vbuf + vwrite + (x * 4 + 2 * half) * 32 * WP;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int nu = 2 * half + q;
+        floatx4 v;
+        if (pr == 0)
+          v = x == 0 ? raw[0 * 4 + nu] - raw[2 * 4 + nu] : raw[1 * 4 + nu] + raw[2 * 4 + nu];
+        else
+          v = x == 0 ? raw[1 * 4 + nu] - raw[0 * 4 + nu] : raw[0 * 4 + nu] - raw[2 * 4 + nu];
+        *(floatx4*)(dst + q * 32 * WP) = v;
       }
     }
   };
@@ -168,16 +177,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
 #pragma unroll
     for (int k = 0; k < 12; ++k) load_one(k);
 #pragma unroll
-    for (int piece = 0; piece < 8; ++piece) transform_piece(piece, lds);
+    for (int piece = 0; piece < 7; ++piece) transform_piece(piece, lds);
     __syncthreads();
   }
   int buf = 0;
-  floatx4 Bq[4];
+  floatx4 Bq[2];
 #pragma unroll
-  for (int f = 0; f < 3; ++f)
+  for (int f = 0; f < 1; ++f)
     Bq[f] = *(const floatx4*)((const char*)(a.u + (size_t)((cur_tile < a.ntiles ? cur_tile : 0) % a.nphase) * a.u_phase_stride +
                                            (size_t)((ph * 8 + f) * Cin8) * wstep) + boff);
-  Bq[3] = Bq[0];
+  Bq[1] = Bq[0];
   while (cur_tile < a.ntiles) {
 #pragma unroll
     for (int p = 0; p < 8; ++p)
@@ -227,10 +236,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
 #pragma unroll
       for (int it = 0; it < 32; ++it) {  // it = sub*8 + p
         {
-          const int f = it + 3;  // U fragment to fetch now
+          const int f = it + 1;  // U fragment to fetch now
           const int fp = f & 7, fs = (f >> 3) & 3;
           const float* src = (f < 32 ? ub : ubn) + (size_t)((ph * 8 + fp) * Cin8 + fs) * wstep;  // uniform
-          Bq[f & 3] = *(const floatx4*)((const char*)src + boff);
+          Bq[f & 1] = *(const floatx4*)((const char*)src + boff);
         }
         if (it < 12) load_one(it);  // producer loads first: they are consumed from step 20 on
         if (it + 1 < 32) {
@@ -242,10 +251,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
           __builtin_amdgcn_s_setprio(1);
 #pragma unroll
           for (int s = 0; s < 4; ++s)
-            acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aq[it & 1][s], Bq[it & 3][s], acc[p0], 0, 0, 0);
+            acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aq[it & 1][s], Bq[it & 1][s], acc[p0], 0, 0, 0);
           __builtin_amdgcn_s_setprio(0);
         }
-        if (it >= 20 && it < 28 && have_next) transform_piece(it - 20, lds + (buf ^ 1) * WBUF);
+        if (it >= 20 && it < 27 && have_next) transform_piece(it - 20, lds + (buf ^ 1) * WBUF);
       }
       STAMP(chunk * 4 + 1);
       STAMP(chunk * 4 + 2);
@@ -260,26 +269,21 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
     // Y[i][j] = (A^T N)[i][j]:  Y[0] = N0 + N1 + N2,  Y[1] = N1 - N2 - N3.
     // ph=0 finishes row i=0 and needs N2 from ph=1; ph=1 finishes i=1 and needs N1 from ph=0.
     STAMP(24);
-    floatx16 n0[2], n1[2];  // [j] for local xi 0 and 1
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (j == 0) {
-        n0[0] = acc[0] + acc[1] + acc[2];
-        n1[0] = acc[4] + acc[5] + acc[6];
-      } else {
-        n0[1] = acc[1] - acc[2] - acc[3];
-        n1[1] = acc[5] - acc[6] - acc[7];
-      }
-    }
-    // exchange area (inside the V buffer that the next tile's first chunk does NOT use)
+    // Register-lean form: keep only this wave's own partial sum per j and hand the other term
+    // to the partner straight away.
+    //   ph=0: own = N0 + N1, sends N1;   ph=1: own = -(N2 + N3), sends N2;   Y = own + received.
     float* xch = lds + (buf ^ 1) * WBUF;  // 4 nt x 2 ph x 2 j x 16 e x 64 lanes = 16384 floats
-    // what the partner needs: ph=0 sends N1 (its local xi=1), ph=1 sends N2 (its local xi=0)
+    floatx16 own[2];
     {
       float* dst = xch + ((nt * 2 + ph) * 2) * 1024 + lane;
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j) {
+        const floatx16 na = j == 0 ? (acc[0] + acc[1]) + acc[2] : (acc[1] - acc[2]) - acc[3];  // local xi 0
+        const floatx16 nb = j == 0 ? (acc[4] + acc[5]) + acc[6] : (acc[5] - acc[6]) - acc[7];  // local xi 1
+        own[j] = ph == 0 ? na + nb : -(na + nb);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) dst[j * 1024 + e * 64] = ph == 0 ? n1[j][e] : n0[j][e];
+        for (int e = 0; e < 16; ++e) dst[j * 1024 + e * 64] = ph == 0 ? nb[e] : na[e];
+      }
     }
     __syncthreads();
     floatx16 yv[2];
@@ -288,11 +292,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float o = src[j * 1024 + e * 64];
-          // ph=0: Y[0] = N0 + N1 + N2(other);  ph=1: Y[1] = N1(other) - N2 - N3
-          yv[j][e] = ph == 0 ? (n0[j][e] + n1[j][e]) + o : (o - n0[j][e]) - n1[j][e];
-        }
+        for (int e = 0; e < 16; ++e) yv[j][e] = own[j][e] + src[j * 1024 + e * 64];
     }
     __syncthreads();  // exchange area free again (it is the next chunk's transform target)
     STAMP(25);
