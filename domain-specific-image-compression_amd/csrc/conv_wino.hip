@@ -43,6 +43,8 @@ struct WinoArgs {
   float* out;
   int B, H, W, Cin, Cout, CoutP;
   int act;
+  unsigned long long* ticket;  // [0] tiles handed out beyond the first round, [1] finished workgroups (zeroed
+                               // once by the caller; the last workgroup of a launch zeroes it again)
   int nphase;  // 1, or 4: ConvTranspose2d(5,2,2,1) as four 3x3 sub-pixel phase convs sharing the input;
                // work item w = spatial tile*4 + phase, U of phase p at u + p*u_phase_stride, output pixel
                // (2*oy+py, 2*ox+px) of a [B,2H,2W,Cout] tensor
@@ -72,6 +74,7 @@ constexpr int WCK = 32;                    // channels per chunk
 constexpr int WP = WCK + 4;                // LDS floats per (pos, tile) row
 constexpr int WBUF = 16 * 32 * WP;         // floats per V buffer
 constexpr int WLDS_BYTES = 2 * WBUF * 4;   // 147456
+constexpr int WLDS_TOTAL = WLDS_BYTES + 16;  // + the next-tile mailbox
 
 // ZSKIP: the launch has structurally zero Winograd positions (space-to-depth input or
 // ConvTranspose2d phases) whose MFMA clusters are skipped; plain 3x3 layers use ZSKIP = false
@@ -172,6 +175,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
   (void)tile_count; (void)stamp_wave;
   const int aread = ((ph * 8) * 32 + l31) * WP + 4 * h;  // + p*32*WP + sub*8
 
+  // Tiles are handed out dynamically (first round = blockIdx.x, then a global ticket): a CU that
+  // is slowed down - e.g. by co-resident waves of another stream - simply takes fewer tiles,
+  // instead of stretching the tail of every launch.  Arithmetic per tile is unchanged.
+  volatile int* mailbox = (volatile int*)(lds + 2 * WBUF);  // [0]: tile after the current one
+  if (tid == 0) mailbox[0] = (int)(atomicAdd(a.ticket, 1ULL) + gridDim.x);
   if (cur_tile < a.ntiles) {
     aim(cur_tile, 0);
 #pragma unroll
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
     for (int p = 0; p < 8; ++p)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
-    const int next_tile = cur_tile + gridDim.x;
+    const int next_tile = mailbox[0];  // written before the last barrier every thread has passed
     const float* u_cur = a.u + (size_t)(cur_tile % a.nphase) * a.u_phase_stride;
     const float* u_nxt = a.u + (size_t)((next_tile < a.ntiles ? next_tile : cur_tile) % a.nphase) * a.u_phase_stride;
     tile_count++;
@@ -345,7 +353,17 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
     STAMP(26);
     __syncthreads();  // transpose patches done before the next tile's producers reuse the area
     STAMP(27);
+    // every thread has read mailbox[0] (next_tile) long before this point (>= 3 barriers ago)
+    if (tid == 0 && next_tile < a.ntiles) mailbox[0] = (int)(atomicAdd(a.ticket, 1ULL) + gridDim.x);
+    __syncthreads();
     cur_tile = next_tile;
+  }
+  if (tid == 0) {  // last workgroup out re-arms the ticket for the next launch on this stream
+    const unsigned long long done = atomicAdd(a.ticket + 1, 1ULL);
+    if (done == (unsigned long long)gridDim.x - 1) {
+      a.ticket[0] = 0ULL;
+      a.ticket[1] = 0ULL;
+    }
   }
 }
 
@@ -458,8 +476,9 @@ static int wino_launch(WinoArgs& a, hipStream_t st);
 
 extern "C" int dsic_conv_transpose2d_wino_nhwc(const float* in, const float* u_packed4, const float* bias,
                                                const float* beta, const float* gamma, float* out, int B,
-                                               int H, int W, int Cin, int Cout, int act, void* stream) {
-  DSIC_REQUIRE(in && u_packed4 && bias && out, "convT_wino: null pointer");
+                                               int H, int W, int Cin, int Cout, int act, void* ticket,
+                                               void* stream) {
+  DSIC_REQUIRE(in && u_packed4 && bias && out && ticket, "convT_wino: null pointer");
   DSIC_REQUIRE(B > 0 && H > 0 && W > 0, "convT_wino: empty tensor");
   DSIC_REQUIRE(Cin > 0 && Cin % 32 == 0, "convT_wino: Cin=%d must be a positive multiple of 32", Cin);
   DSIC_REQUIRE(Cout > 0 && Cout % 4 == 0 && Cout <= 128, "convT_wino: Cout=%d must be a multiple of 4, <= 128", Cout);
@@ -468,6 +487,7 @@ extern "C" int dsic_conv_transpose2d_wino_nhwc(const float* in, const float* u_p
   WinoArgs a{};
   a.in = in; a.u = u_packed4; a.bias = bias; a.beta = beta; a.gamma = gamma; a.out = out;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.CoutP = round_up(Cout, 32); a.act = act;
+  a.ticket = (unsigned long long*)ticket;
   a.s2d = 0; a.s2d_in = 0; a.nphase = 4; a.u_phase_stride = dsic_wino_weight_floats(Cout, Cin);
   return wino_launch(a, (hipStream_t)stream);
 }
@@ -475,8 +495,8 @@ extern "C" int dsic_conv_transpose2d_wino_nhwc(const float* in, const float* u_p
 extern "C" int dsic_conv3x3_wino_nhwc(const float* in, const float* u_packed, const float* bias,
                                       const float* beta, const float* gamma, float* out, int B, int H,
                                       int W, int Cin, int Cout, int act, int s2d_out, int s2d_in,
-                                      void* stream) {
-  DSIC_REQUIRE(in && u_packed && bias && out, "conv3x3_wino: null pointer");
+                                      void* ticket, void* stream) {
+  DSIC_REQUIRE(in && u_packed && bias && out && ticket, "conv3x3_wino: null pointer");
   DSIC_REQUIRE(B > 0 && H > 0 && W > 0, "conv3x3_wino: empty tensor");
   DSIC_REQUIRE(Cin > 0 && Cin % 32 == 0, "conv3x3_wino: Cin=%d must be a positive multiple of 32", Cin);
   DSIC_REQUIRE(Cout > 0 && Cout % 4 == 0 && Cout <= 128, "conv3x3_wino: Cout=%d must be a multiple of 4, <= 128", Cout);
@@ -487,6 +507,7 @@ extern "C" int dsic_conv3x3_wino_nhwc(const float* in, const float* u_packed, co
   DSIC_REQUIRE(!s2d_out || (H % 2 == 0 && W % 2 == 0), "conv3x3_wino: space-to-depth output needs even H and W");
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.CoutP = round_up(Cout, 32); a.act = act;
   a.s2d = s2d_out;
+  a.ticket = (unsigned long long*)ticket;
   DSIC_REQUIRE(!s2d_in || Cin % 128 == 0, "conv3x3_wino: space-to-depth input needs Cin = 4*Cs with Cs %% 32 == 0");
   a.s2d_in = s2d_in ? 1 : 0;
   a.nphase = 1; a.u_phase_stride = 0;
@@ -502,10 +523,10 @@ static int wino_launch(WinoArgs& a, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv_wino_kernel<false>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, WLDS_BYTES);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, WLDS_TOTAL);
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)conv_wino_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              WLDS_BYTES);
+                              WLDS_TOTAL);
     if (e != hipSuccess) {
       set_error("conv3x3_wino: hipFuncSetAttribute: %s", hipGetErrorString(e));
       return DSIC_EHIP;
@@ -522,8 +543,8 @@ static int wino_launch(WinoArgs& a, hipStream_t st) {
   }
   const int grid = a.ntiles < max_grid ? a.ntiles : max_grid;
   if (a.s2d_in || a.nphase == 4)
-    hipLaunchKernelGGL(conv_wino_kernel<true>, dim3(grid), dim3(512), WLDS_BYTES, st, a);
+    hipLaunchKernelGGL(conv_wino_kernel<true>, dim3(grid), dim3(512), WLDS_TOTAL, st, a);
   else
-    hipLaunchKernelGGL(conv_wino_kernel<false>, dim3(grid), dim3(512), WLDS_BYTES, st, a);
+    hipLaunchKernelGGL(conv_wino_kernel<false>, dim3(grid), dim3(512), WLDS_TOTAL, st, a);
   return check_launch("conv3x3_wino");
 }

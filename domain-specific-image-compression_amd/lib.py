@@ -35,10 +35,11 @@ SIGNATURES = {
     "dsic_wino_weight_floats": (c_int64, [c_int, c_int]),
     "dsic_pack_wino_weight": (c_int, [_P, _P, c_int, c_int, _P]),
     "dsic_conv3x3_wino_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                       _P]),
+                                       _P, _P]),
     "dsic_pack_wino_s2_weight": (c_int, [_P, _P, c_int, c_int, _P]),
     "dsic_pack_wino_convT_weight": (c_int, [_P, _P, c_int, c_int, _P]),
-    "dsic_conv_transpose2d_wino_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "dsic_conv_transpose2d_wino_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P,
+                                                _P]),
     "dsic_conv_first_nchw": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "dsic_conv_transpose2d_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int,
                                            c_int, c_int, _P]),

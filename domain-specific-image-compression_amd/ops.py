@@ -167,6 +167,19 @@ def pack_wino_s2_weight(w: torch.Tensor) -> torch.Tensor:
     return dst
 
 
+_tickets = {}
+
+
+def _ticket(device):
+    """16 zeroed bytes per (device, stream): the persistent Winograd kernel's tile ticket."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = _tickets.get(key)
+    if t is None:
+        t = torch.zeros(2, dtype=torch.int64, device=device)
+        _tickets[key] = t
+    return t
+
+
 def pack_wino_convT_weight(w: torch.Tensor) -> torch.Tensor:
     """ConvTranspose2d weight [Cin,Cout,5,5] -> Winograd U of its four 3x3 sub-pixel phase convs."""
     w = _f32c(w, "pack_wino_convT_weight")
@@ -189,7 +202,8 @@ def conv_transpose2d_wino_nhwc(x, u_packed4, bias, Cout, act=ACT_NONE, beta=None
     wino_tiles = 4 * B * (-(-H // 8)) * (-(-W // 16)) * 32
     _timed("conv_wino_kernel<1>", 2.0 * B * H * W * Cout * Cin * 25,
            lambda: _lib.check(L.dsic_conv_transpose2d_wino_nhwc(_p(x), _p(u_packed4), _p(bias), _p(beta), _p(gamma),
-                                                                _p(out), B, H, W, Cin, Cout, act, _stream()),
+                                                                _p(out), B, H, W, Cin, Cout, act, _p(_ticket(x.device)),
+                                                                _stream()),
                               "conv_transpose2d_wino_nhwc"),
            exec_flops=2.0 * wino_tiles * 12.25 * Cin * round_up(Cout, 32))
     return out
@@ -223,7 +237,7 @@ def conv3x3_wino_nhwc(x, u_packed, bias, Cout, act=ACT_NONE, beta=None, gamma=No
            algo_flops if algo_flops is not None else 2.0 * B * H * W * Cout * Cin * 9,
            lambda: _lib.check(L.dsic_conv3x3_wino_nhwc(_p(x), _p(u_packed), _p(bias), _p(beta), _p(gamma), _p(out),
                                                        B, H, W, Cin, Cout, act, int(bool(s2d_out)), int(bool(s2d_in)),
-                                                       _stream()),
+                                                       _p(_ticket(x.device)), _stream()),
                               "conv3x3_wino_nhwc"),
            exec_flops=2.0 * wino_tiles * (12.25 if s2d_in else 16) * Cin * round_up(Cout, 32))
     return out

@@ -100,7 +100,9 @@ int dsic_conv2d_nhwc(const float* in, const float* w_packed, const float* bias,
  * fp32 MFMA (layers.py:56,62,67,86,90,94,108,109): 2.25x fewer multiplies than
  * dsic_conv2d_nhwc, same fp32 operands.  u_packed from dsic_pack_wino_weight
  * (G g G^T per (cout,cin), [16][Cin/8][CoutP][8]).  Cin % 32 == 0, Cout % 4 == 0,
- * Cout <= 128.  in NHWC [B,H,W,Cin] -> out NHWC [B,H,W,Cout]. */
+ * Cout <= 128.  in NHWC [B,H,W,Cin] -> out NHWC [B,H,W,Cout].  ticket: 16 bytes of device
+ * memory zeroed ONCE by the caller (dynamic tile hand-out of the persistent kernel; each launch
+ * leaves it zeroed again; launches sharing a ticket must be ordered on one stream). */
 int64_t dsic_wino_weight_floats(int Cout, int Cin);
 int dsic_pack_wino_weight(const float* w_oihw, float* dst, int Cout, int Cin,
                           void* stream);
@@ -108,7 +110,7 @@ int dsic_conv3x3_wino_nhwc(const float* in, const float* u_packed,
                            const float* bias, const float* beta,
                            const float* gamma, float* out, int B, int H, int W,
                            int Cin, int Cout, int act, int s2d_out, int s2d_in,
-                           void* stream);
+                           void* ticket, void* stream);
 /* conv(Cs,Cout,5,2) (layers.py:54,60,65) as a 3x3 stride-1 Winograd conv over the
  * space-to-depth input [B,H/2,W/2,4*Cs] (channel (a*2+b)*Cs+c = x[2i+a][2j+b][c],
  * written by the producing layer when its s2d_out flag is set): 16 instead of
@@ -130,7 +132,7 @@ int dsic_conv_transpose2d_wino_nhwc(const float* in, const float* u_packed4,
                                     const float* bias, const float* beta,
                                     const float* gamma, float* out, int B,
                                     int H, int W, int Cin, int Cout, int act,
-                                    void* stream);
+                                    void* ticket, void* stream);
 
 /* First analysis layer conv(Cimg,Cout,3,1) + optional GDN/ReLU (layers.py:51)
  * read straight from the NCHW image [B,Cimg,H,W] (Cimg 3 or 4) with K = 9*Cimg;
