@@ -33,6 +33,7 @@ namespace dsic {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef int intx4 __attribute__((ext_vector_type(4)));
 
 struct WinoArgs {
   const float* in;
@@ -74,182 +75,234 @@ constexpr int WCK = 32;                    // channels per chunk
 constexpr int WP = WCK + 4;                // LDS floats per (pos, tile) row
 constexpr int WBUF = 16 * 32 * WP;         // floats per V buffer
 constexpr int WLDS_BYTES = 2 * WBUF * 4;   // 147456
-constexpr int WLDS_TOTAL = WLDS_BYTES + 16;  // + the next-tile mailbox
+constexpr int WLDS_TOTAL = WLDS_BYTES + 48;  // + three tile-descriptor slots
+constexpr int WTHREADS = 768;              // 8 MFMA waves + 4 helper waves
+#ifndef WINO_RING
+#define WINO_RING 4                        // U fragments in flight per MFMA wave (2 or 4)
+#endif
+
+__device__ __forceinline__ void wg_barrier() { __syncthreads(); }
+
+struct WinoTile {
+  int item, tx, ty, n;  // work item (tile*nphase + phase) and its 16x8-pixel tile coordinates
+};
 
 // ZSKIP: the launch has structurally zero Winograd positions (space-to-depth input or
 // ConvTranspose2d phases) whose MFMA clusters are skipped; plain 3x3 layers use ZSKIP = false
 // and carry no test in the loop.
-// Register budget: the kernel must stay at <= 240 VGPRs.  Two of these waves per SIMD then leave 32
-// of the 512-entry file, so a small wave of another stream (the serial range coder, 24 VGPRs) can
-// stay resident beside this persistent kernel instead of waiting for a CU to drain.  Hence the U
-// ring is only two deep (a deeper ring measured no faster).
+//
+// Wave specialisation.  Waves 0..7 ("MFMA waves") only read operands and issue MFMAs; waves 8..11
+// ("helpers", one per SIMD) load the NHWC input, apply B^T d B and fill the other LDS buffer.
+// vmcnt retires in order, so a wave that mixes HBM-latency input loads with the L2-latency U
+// stream stalls its MFMAs behind the slowest input load; separate waves have separate counters.
+// 12 waves = 3 per SIMD: the kernel must fit 168 VGPRs (128 of them accumulators).
+// Every wave executes the same barrier sequence: P0, P, then per tile B_0..B_{n-1}, E1, E2, E3.
+//
+// Tiles are handed out dynamically (first round = blockIdx.x, then a global ticket): a CU that is
+// slowed down - e.g. by co-resident waves of another stream - simply takes fewer tiles.  Helper
+// thread 0 fetches the ticket one tile ahead, splits it into (tx, ty, n) (the only integer
+// divisions of the kernel) and posts the descriptor in a 3-slot LDS ring: slot k%3 = the k-th
+// tile of this workgroup.
 template <bool ZSKIP>
-__global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
+__global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = lane >> 5, l31 = lane & 31;
-  const int nt = wave & 3, ph = wave >> 2;
-  const int Cin = a.Cin, Cin8 = Cin >> 3;
-  const int nchunks = Cin / WCK;
-  const bool nvalid = nt * 32 < a.CoutP;
-  const int wstep = a.CoutP * 8;
-  const unsigned boff = (unsigned)((((nvalid ? nt : 0) * 32 + l31) * 8 + 4 * h) * 4);  // bytes
-
-  // producer role of this thread: Winograd tile pt, channel quad pq, position half pr
-  const int pt = tid >> 4, pq = tid & 7, pr = (tid >> 3) & 1;  // 8 adjacent lanes = 128 contiguous bytes
-  const int ptx = pt & 7, pty = pt >> 3;
-  // pr = 0 computes xi in {0,1} from input rows 0,1,2; pr = 1 computes xi in {2,3} from rows 1,2,3
-  const int vwrite = ((pr * 8) * 32 + pt) * WP + 4 * pq;  // + (xi_local*4 + nu)*32*WP
-
-  floatx4 raw[12];
-  int cur_tile = blockIdx.x;
-  // ---- producer: the 3x4 pixel patch of (tile, chunk) this thread loads ---------------------
-  // Loads are issued ONE AT A TIME between MFMA clusters (vmcnt retires in order: a burst of
-  // 12 loads in front of the U-fragment loads would stall the first cluster of every chunk
-  // for a full memory latency).  Out-of-image pixels load a clamped address and are zeroed
-  // in the transform, so the load itself is branch-free.
-  int ld_gy0 = 0, ld_gx0 = 0;
-  bool ld_border = true;  // the 18x10 window of the aimed tile leaves the image somewhere
-  const char* ld_base = (const char*)a.in;  // wave-uniform: image + chunk; lanes add a 32-bit byte offset
-  auto aim = [&](int item, int chunk) {
-    const int tile = item / a.nphase;
-    const int tx = tile % a.tiles_x;
-    const int ty = (tile / a.tiles_x) % a.tiles_y;
-    const int n = tile / (a.tiles_x * a.tiles_y);
-    ld_border = ty == 0 || tx == 0 || ty * 8 + 9 > a.H || tx * 16 + 17 > a.W;
-    ld_gy0 = ty * 8 + 2 * pty - 1 + pr;
-    ld_gx0 = tx * 16 + 2 * ptx - 1;
-    ld_base = (const char*)(a.in + (size_t)n * a.H * a.W * Cin + chunk * WCK);
+  float* slots = lds + 2 * WBUF;  // written before a workgroup barrier, read after it
+  auto read_slot = [&](int s) {
+    const intx4 v = *(const intx4*)(slots + 4 * s);
+    WinoTile t;
+    t.item = __builtin_amdgcn_readfirstlane(v[0]);
+    t.tx = __builtin_amdgcn_readfirstlane(v[1]);
+    t.ty = __builtin_amdgcn_readfirstlane(v[2]);
+    t.n = __builtin_amdgcn_readfirstlane(v[3]);
+    return t;
   };
-  auto load_one = [&](int k) {
-    int gy = ld_gy0 + (k >> 2), gx = ld_gx0 + (k & 3);
-    gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
-    gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
-    const unsigned off = (unsigned)(((gy * a.W + gx) * Cin + 4 * pq) * 4);
-    raw[k] = *(const floatx4*)(ld_base + off);
-  };
-  // ---- producer: B^T d B for this thread's two xi rows, in 8 pieces that are issued between
-  // MFMA clusters (VALU and LDS writes ride in the shadow of the 64-cycle MFMAs) ---------------
-  // Columns first, in place (d B needs one window row at a time and overwrites it), rows second
-  // with the results stored straight to LDS: no intermediate tile, 32 fewer live registers.
-  //   pieces 0..2: local row i:  (w0,w1,w2,w3) = (d0-d2, d1+d2, d2-d1, d1-d3), out-of-image zeroed
-  //   pieces 3..6: xi row x = (piece-3)>>1, nu pair (piece-3)&1:  xi0 = r0-r2, xi1 = r1+r2  (pr=0)
-  //                                                               xi2 = r1-r0, xi3 = r0-r2  (pr=1, rows d1,d2,d3)
-  auto transform_piece = [&](int piece, float* vbuf) {
-    if (piece < 3) {
-      const int i = piece;
-      floatx4 d0 = raw[i * 4 + 0], d1 = raw[i * 4 + 1], d2 = raw[i * 4 + 2], d3 = raw[i * 4 + 3];
-      if (ld_border) {
-        const int gy = ld_gy0 + i;
-        const bool yok = gy >= 0 && gy < a.H;
-        const floatx4 z = {0.f, 0.f, 0.f, 0.f};
-        if (!(yok && ld_gx0 >= 0 && ld_gx0 < a.W)) d0 = z;
-        if (!(yok && ld_gx0 + 1 >= 0 && ld_gx0 + 1 < a.W)) d1 = z;
-        if (!(yok && ld_gx0 + 2 >= 0 && ld_gx0 + 2 < a.W)) d2 = z;
-        if (!(yok && ld_gx0 + 3 >= 0 && ld_gx0 + 3 < a.W)) d3 = z;
-      }
-      raw[i * 4 + 0] = d0 - d2;
-      raw[i * 4 + 1] = d1 + d2;
-      raw[i * 4 + 2] = d2 - d1;
-      raw[i * 4 + 3] = d1 - d3;
-    } else {
-      const int x = (piece - 3) >> 1, half = (piece - 3) & 1;
-      float* dst = vbuf + vwrite + (x * 4 + 2 * half) * 32 * WP;
+  const int pshift = a.nphase == 4 ? 2 : 0;
+
+  if (wave >= 8) {
+    // =================================== helper waves ===========================================
+    // thread = (Winograd tile pt, channel quad pq): the whole 4x4 pixel patch, 16 float4 loads
+    // (8 adjacent lanes = 128 contiguous bytes), all 16 positions.
+    const int ht = tid - 512;
+    const int Cin = a.Cin;
+    const int nchunks = Cin / WCK;
+    const int pt = ht >> 3, pq = ht & 7;
+    const int ptx = pt & 7, pty = pt >> 3;
+    const int vwrite = pt * WP + 4 * pq;  // + pos*32*WP
+    auto post = [&](int s, int item) {  // helper thread 0 only
+      const int tile = item >> pshift;
+      const int row = tile / a.tiles_x;
+      const intx4 v = {item, tile - row * a.tiles_x, row % a.tiles_y, row / a.tiles_y};
+      *(intx4*)(slots + 4 * s) = v;
+    };
+    auto produce = [&](const WinoTile& t, int chunk, float* vbuf) {
+      const bool border = t.ty == 0 || t.tx == 0 || t.ty * 8 + 9 > a.H || t.tx * 16 + 17 > a.W;  // uniform
+      const int gy0 = t.ty * 8 + 2 * pty - 1, gx0 = t.tx * 16 + 2 * ptx - 1;
+      const char* base = (const char*)(a.in + (size_t)t.n * a.H * a.W * Cin + chunk * WCK);
+      floatx4 d[16];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int nu = 2 * half + q;
-        floatx4 v;
-        if (pr == 0)
-          v = x == 0 ? raw[0 * 4 + nu] - raw[2 * 4 + nu] : raw[1 * 4 + nu] + raw[2 * 4 + nu];
-        else
-          v = x == 0 ? raw[1 * 4 + nu] - raw[0 * 4 + nu] : raw[0 * 4 + nu] - raw[2 * 4 + nu];
-        *(floatx4*)(dst + q * 32 * WP) = v;
+      for (int i = 0; i < 4; ++i) {
+        int gy = gy0 + i;
+        gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);  // out-of-image pixels load a clamped address, zeroed below
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          int gx = gx0 + k;
+          gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+          const unsigned off = (unsigned)(((gy * a.W + gx) * Cin + 4 * pq) * 4);
+          d[i * 4 + k] = *(const floatx4*)(base + off);
+        }
+      }
+      if (border) {
+        const floatx4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool yok = gy0 + i >= 0 && gy0 + i < a.H;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (!(yok && gx0 + k >= 0 && gx0 + k < a.W)) d[i * 4 + k] = z;
+        }
+      }
+      // columns, in place: (w0,w1,w2,w3) = (d0-d2, d1+d2, d2-d1, d1-d3)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const floatx4 d0 = d[i * 4 + 0], d1 = d[i * 4 + 1], d2 = d[i * 4 + 2], d3 = d[i * 4 + 3];
+        d[i * 4 + 0] = d0 - d2;
+        d[i * 4 + 1] = d1 + d2;
+        d[i * 4 + 2] = d2 - d1;
+        d[i * 4 + 3] = d1 - d3;
+      }
+      // rows, straight to LDS: xi0 = r0-r2, xi1 = r1+r2, xi2 = r2-r1, xi3 = r1-r3
+      float* dst = vbuf + vwrite;
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) {
+        const floatx4 r0 = d[0 * 4 + nu], r1 = d[1 * 4 + nu], r2 = d[2 * 4 + nu], r3 = d[3 * 4 + nu];
+        *(floatx4*)(dst + (0 * 4 + nu) * 32 * WP) = r0 - r2;
+        *(floatx4*)(dst + (1 * 4 + nu) * 32 * WP) = r1 + r2;
+        *(floatx4*)(dst + (2 * 4 + nu) * 32 * WP) = r2 - r1;
+        *(floatx4*)(dst + (3 * 4 + nu) * 32 * WP) = r1 - r3;
+      }
+    };
+    if (ht == 0) {
+      post(0, (int)blockIdx.x);  // grid <= ntiles
+      post(1, (int)(atomicAdd(a.ticket, 1ULL) + gridDim.x));
+    }
+    wg_barrier();  // P0: the first two descriptors are posted
+    WinoTile cur = read_slot(0);
+    produce(cur, 0, lds);
+    wg_barrier();  // P
+    int buf = 0, s_nxt = 1, s_wr = 2;
+    while (cur.item < a.ntiles) {
+      const WinoTile nxt = read_slot(s_nxt);
+      for (int chunk = 0; chunk < nchunks; ++chunk) {
+        float* vnext = lds + (buf ^ 1) * WBUF;
+        if (chunk + 1 < nchunks)
+          produce(cur, chunk + 1, vnext);
+        else if (nxt.item < a.ntiles)
+          produce(nxt, 0, vnext);
+        if (chunk == 0 && ht == 0 && nxt.item < a.ntiles)
+          post(s_wr, (int)(atomicAdd(a.ticket, 1ULL) + gridDim.x));
+        wg_barrier();  // B_chunk
+        buf ^= 1;
+      }
+      wg_barrier();  // E1
+      wg_barrier();  // E2
+      wg_barrier();  // E3: the MFMA waves' exchange/transpose area (= V[buf^1]) is free again
+      cur = nxt;
+      const int s_old = s_nxt;
+      s_nxt = s_wr;
+      s_wr = s_old == 0 ? 2 : s_old - 1;  // ring 0,1,2: cur slot of the finished tile becomes writable
+    }
+    if (ht == 0) {  // last workgroup out re-arms the ticket for the next launch on this stream
+      const unsigned long long done = atomicAdd(a.ticket + 1, 1ULL);
+      if (done == (unsigned long long)gridDim.x - 1) {
+        a.ticket[0] = 0ULL;
+        a.ticket[1] = 0ULL;
       }
     }
-  };
+    return;
+  }
+
+  // ===================================== MFMA waves ==============================================
+  // Wave w owns column tile nt = w&3 (32 output channels) and positions 8*(w>>2) .. +7.
+  const int h = lane >> 5, l31 = lane & 31;
+  const int nt = wave & 3, ph = wave >> 2;
+  const bool nvalid = nt * 32 < a.CoutP;
+  const int nchunks = a.Cin / WCK;
+  // U stream: packed [pos][Cin/8][CoutP][8] floats; the fetch position advances by one position
+  // (step_p bytes) per fragment and wraps to the next 8-channel group after 8 of them.  Kept as
+  // one 32-bit lane offset against a uniform 64-bit base, so no per-fragment address is hoisted.
+  const unsigned step_s = (unsigned)a.CoutP * 32u;             // bytes per 8-channel group
+  const unsigned step_p = (unsigned)(a.Cin >> 3) * step_s;    // bytes per position
+  const unsigned step_wrap = step_s - 7u * step_p;             // p = 7 -> p = 0 of the next group
+  const unsigned tile_wrap = (unsigned)(a.Cin >> 3) * step_s;  // all channel groups of a tile (= step_p)
+  const unsigned voff0 = (unsigned)ph * 8u * step_p + (unsigned)((((nvalid ? nt : 0) * 32 + l31) * 8 + 4 * h) * 4);
+  const int aread = ((ph * 8) * 32 + l31) * WP + 4 * h;  // + p*32*WP + sub*8
+  const int stamp_wave = 0;
+  int tile_count = 0;
+  (void)stamp_wave; (void)tile_count;
+  constexpr int R = WINO_RING;
+  static_assert(R == 2 || R == 4, "ring depth must divide the 32 steps of a chunk");
 
   floatx16 acc[8];
-  int tile_count = 0;
-  const int stamp_wave = 0;
-  (void)tile_count; (void)stamp_wave;
-  const int aread = ((ph * 8) * 32 + l31) * WP + 4 * h;  // + p*32*WP + sub*8
-
-  // Tiles are handed out dynamically (first round = blockIdx.x, then a global ticket): a CU that
-  // is slowed down - e.g. by co-resident waves of another stream - simply takes fewer tiles,
-  // instead of stretching the tail of every launch.  Arithmetic per tile is unchanged.
-  volatile int* mailbox = (volatile int*)(lds + 2 * WBUF);  // [0]: tile after the current one
-  if (tid == 0) mailbox[0] = (int)(atomicAdd(a.ticket, 1ULL) + gridDim.x);
-  if (cur_tile < a.ntiles) {
-    aim(cur_tile, 0);
+  floatx4 Bq[R];
+  wg_barrier();  // P0
+  wg_barrier();  // P
+  WinoTile cur = read_slot(0);
+  const char* ubase = (const char*)(a.u + (size_t)(cur.item & (a.nphase - 1)) * a.u_phase_stride);  // of the fetch stream
+  unsigned voff = voff0;  // fetch stream position
+  auto fetch = [&](int f) {  // fragment f = sub*8 + p of the stream; advances the position
+    const floatx4 v = *(const floatx4*)(ubase + voff);
+    voff += (f & 7) == 7 ? step_wrap : step_p;
+    return v;
+  };
 #pragma unroll
-    for (int k = 0; k < 12; ++k) load_one(k);
-#pragma unroll
-    for (int piece = 0; piece < 7; ++piece) transform_piece(piece, lds);
-    __syncthreads();
-  }
-  int buf = 0;
-  floatx4 Bq[2];
-#pragma unroll
-  for (int f = 0; f < 1; ++f)
-    Bq[f] = *(const floatx4*)((const char*)(a.u + (size_t)((cur_tile < a.ntiles ? cur_tile : 0) % a.nphase) * a.u_phase_stride +
-                                           (size_t)((ph * 8 + f) * Cin8) * wstep) + boff);
-  Bq[1] = Bq[0];
-  while (cur_tile < a.ntiles) {
+  for (int f = 0; f < R - 1; ++f) Bq[f] = fetch(f);
+  int buf = 0, s_nxt = 1;
+  while (cur.item < a.ntiles) {
 #pragma unroll
     for (int p = 0; p < 8; ++p)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
-    const int next_tile = mailbox[0];  // written before the last barrier every thread has passed
-    const float* u_cur = a.u + (size_t)(cur_tile % a.nphase) * a.u_phase_stride;
-    const float* u_nxt = a.u + (size_t)((next_tile < a.ntiles ? next_tile : cur_tile) % a.nphase) * a.u_phase_stride;
+    const WinoTile nxt = read_slot(s_nxt);
+    const char* ubase_nxt =
+        (const char*)(a.u + (size_t)((nxt.item < a.ntiles ? nxt.item : cur.item) & (a.nphase - 1)) * a.u_phase_stride);
     tile_count++;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
       STAMP(chunk * 4 + 0);
-      // aim the producer at the next (tile, chunk); past the end it re-reads valid data
       const bool last = chunk + 1 == nchunks;
-      const bool have_next = !last || next_tile < a.ntiles;
-      aim(last ? (next_tile < a.ntiles ? next_tile : cur_tile) : cur_tile, last ? 0 : chunk + 1);
-      // consumer: 8 positions x 4 sub-chunks x 4 k-steps.  U fragments run in a 4-deep
-      // register ring three steps ahead (L2 latency), continuous across chunks and tiles
-      // (U does not depend on the tile); V fragments one step ahead (LDS latency).
       // Structurally zero Winograd positions: a 3-tap filter with a zero end tap has a zero
       // transform component (G (g0,g1,0)^T)[3] = 0, (G (0,g1,g2)^T)[0] = 0.  For the space-to-depth
       // form of a 5x5/s2 kernel the phases a=1 / b=1 lack the last row / column (xi=3 / nu=3
       // vanish); for a ConvTranspose2d phase py=1 / px=1 lacks the first row / column (xi=0 /
       // nu=0 vanish).  Those MFMA clusters are skipped: 49 instead of 64 position-phase GEMMs.
-      unsigned zero_xi = 4, zero_nu = 4, zero_xi_n = 4, zero_nu_n = 4;  // this chunk / the next one; 4 = none
+      unsigned zero_xi = 4, zero_nu = 4;  // 4 = none
       if (ZSKIP && a.s2d_in) {
-        const int per = nchunks >> 2;
-        const int blk = chunk / per;  // channel block (a,b) = (blk>>1, blk&1)
-        const int blk_n = last ? 0 : (chunk + 1) / per;
+        const int blk = chunk / (nchunks >> 2);  // channel block (a,b) = (blk>>1, blk&1)
         if (blk >> 1) zero_xi = 3;
         if (blk & 1) zero_nu = 3;
-        if (blk_n >> 1) zero_xi_n = 3;
-        if (blk_n & 1) zero_nu_n = 3;
       } else if (ZSKIP && a.nphase == 4) {
-        const int phase = cur_tile & 3;  // grid is a multiple of 4: the next item has the same phase
-        if (phase >> 1) zero_xi = zero_xi_n = 0;
-        if (phase & 1) zero_nu = zero_nu_n = 0;
+        const int phase = cur.item & 3;
+        if (phase >> 1) zero_xi = 0;
+        if (phase & 1) zero_nu = 0;
       }
-      auto is_zero = [&](int f) {  // step f of this chunk (f < 32) or f-32 of the next
+      auto is_zero = [&](int f) {
         const unsigned xi = (unsigned)(ph * 2 + ((f & 7) >> 2)), nu = (unsigned)(f & 3);
-        return f < 32 ? (xi == zero_xi || nu == zero_nu) : (xi == zero_xi_n || nu == zero_nu_n);
+        return xi == zero_xi || nu == zero_nu;
       };
       const float* vb = lds + buf * WBUF + aread;
-      const float* ub = u_cur + (size_t)(chunk * 4) * wstep;
-      const float* ubn = last ? u_nxt : u_cur + (size_t)((chunk + 1) * 4) * wstep;
       floatx4 Aq[2];
       Aq[0] = *(const floatx4*)(vb);
 #pragma unroll
       for (int it = 0; it < 32; ++it) {  // it = sub*8 + p
         {
-          const int f = it + 1;  // U fragment to fetch now
-          const int fp = f & 7, fs = (f >> 3) & 3;
-          const float* src = (f < 32 ? ub : ubn) + (size_t)((ph * 8 + fp) * Cin8 + fs) * wstep;  // uniform
-          Bq[f & 1] = *(const floatx4*)((const char*)src + boff);
+          const int f = it + R - 1;  // U fragment to fetch now (continuous across chunks and tiles)
+          if (f == 32 && last) {     // the stream moves on to the next tile: its phase's U, first group
+            ubase = ubase_nxt;
+            voff -= tile_wrap;
+          }
+          Bq[f % R] = fetch(f);
         }
-        if (it < 12) load_one(it);  // producer loads first: they are consumed from step 20 on
         if (it + 1 < 32) {
           const int p1 = (it + 1) & 7, s1 = (it + 1) >> 3;
           Aq[(it + 1) & 1] = *(const floatx4*)(vb + p1 * 32 * WP + s1 * 8);
@@ -259,14 +312,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
           __builtin_amdgcn_s_setprio(1);
 #pragma unroll
           for (int s = 0; s < 4; ++s)
-            acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aq[it & 1][s], Bq[it & 1][s], acc[p0], 0, 0, 0);
+            acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aq[it & 1][s], Bq[it % R][s], acc[p0], 0, 0, 0);
           __builtin_amdgcn_s_setprio(0);
         }
-        if (it >= 20 && it < 27 && have_next) transform_piece(it - 20, lds + (buf ^ 1) * WBUF);
       }
       STAMP(chunk * 4 + 1);
       STAMP(chunk * 4 + 2);
-      __syncthreads();
+      wg_barrier();  // B_chunk
       STAMP(chunk * 4 + 3);
       buf ^= 1;
     }
@@ -293,7 +345,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
         for (int e = 0; e < 16; ++e) dst[j * 1024 + e * 64] = ph == 0 ? nb[e] : na[e];
       }
     }
-    __syncthreads();
+    wg_barrier();  // E1
     floatx16 yv[2];
     {
       const float* src = xch + ((nt * 2 + (ph ^ 1)) * 2) * 1024 + lane;
@@ -302,14 +354,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) yv[j][e] = own[j][e] + src[j * 1024 + e * 64];
     }
-    __syncthreads();  // exchange area free again (it is the next chunk's transform target)
+    wg_barrier();  // E2: exchange area becomes the per-wave transpose scratch
     STAMP(25);
 
     if (nvalid) {
-      const int stile = cur_tile / a.nphase, phase = cur_tile % a.nphase;
-      const int tx = stile % a.tiles_x;
-      const int ty = (stile / a.tiles_x) % a.tiles_y;
-      const int n = stile / (a.tiles_x * a.tiles_y);
+      const int phase = cur.item & (a.nphase - 1);
+      const int tx = cur.tx, ty = cur.ty, n = cur.n;
       const int up = a.nphase == 4 ? 2 : 1, ppy = phase >> 1, ppx = phase & 1;  // sub-pixel phase placement
       const int col = nt * 32 + l31;
       const bool cok = col < a.Cout;
@@ -319,7 +369,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
         beta = a.beta[col];
         gamma = a.gamma[col];
       }
-      // per-wave transpose patch: overlays the exchange area, which is free after the barrier above
       float* epi = xch + wave * (32 * 36);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -351,19 +400,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoArgs a) {
       }
     }
     STAMP(26);
-    __syncthreads();  // transpose patches done before the next tile's producers reuse the area
+    wg_barrier();  // E3: transpose patches done before the helpers reuse the area
     STAMP(27);
-    // every thread has read mailbox[0] (next_tile) long before this point (>= 3 barriers ago)
-    if (tid == 0 && next_tile < a.ntiles) mailbox[0] = (int)(atomicAdd(a.ticket, 1ULL) + gridDim.x);
-    __syncthreads();
-    cur_tile = next_tile;
-  }
-  if (tid == 0) {  // last workgroup out re-arms the ticket for the next launch on this stream
-    const unsigned long long done = atomicAdd(a.ticket + 1, 1ULL);
-    if (done == (unsigned long long)gridDim.x - 1) {
-      a.ticket[0] = 0ULL;
-      a.ticket[1] = 0ULL;
-    }
+    cur = nxt;
+    s_nxt = s_nxt == 2 ? 0 : s_nxt + 1;
   }
 }
 
@@ -543,8 +583,8 @@ static int wino_launch(WinoArgs& a, hipStream_t st) {
   }
   const int grid = a.ntiles < max_grid ? a.ntiles : max_grid;
   if (a.s2d_in || a.nphase == 4)
-    hipLaunchKernelGGL(conv_wino_kernel<true>, dim3(grid), dim3(512), WLDS_TOTAL, st, a);
+    hipLaunchKernelGGL(conv_wino_kernel<true>, dim3(grid), dim3(WTHREADS), WLDS_TOTAL, st, a);
   else
-    hipLaunchKernelGGL(conv_wino_kernel<false>, dim3(grid), dim3(512), WLDS_TOTAL, st, a);
+    hipLaunchKernelGGL(conv_wino_kernel<false>, dim3(grid), dim3(WTHREADS), WLDS_TOTAL, st, a);
   return check_launch("conv3x3_wino");
 }
