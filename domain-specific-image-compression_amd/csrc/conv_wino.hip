@@ -23,10 +23,15 @@
 // per lane through the LDS transpose.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 #ifndef WINO_STAMP
 #define WINO_STAMP 0
+#endif
+#ifndef WINO_STAMP_TILE
+#define WINO_STAMP_TILE 16  // which tile of a workgroup is stamped
 #endif
 
 namespace dsic {
@@ -34,6 +39,7 @@ namespace dsic {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef int intx4 __attribute__((ext_vector_type(4)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
 
 struct WinoArgs {
   const float* in;
@@ -66,19 +72,31 @@ __device__ __forceinline__ float wino_act(float v, int act, float beta, float ga
 
 #if WINO_STAMP
 __device__ long long wino_stamps[256 * 32];
-#define STAMP(i) if (WINO_STAMP && lane == 0 && wave == stamp_wave && tile_count == 2) wino_stamps[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime()
+// cycle stamps go to LDS (a global store would sit in the wave's in-order vmcnt queue and perturb
+// what is measured) and are copied out when the workgroup ends
+#define STAMP_AT(w, i) \
+  if (WINO_STAMP && lane == 0 && wave == (w) && tile_count == WINO_STAMP_TILE) ((long long*)(lds + 2 * WBUF + 16))[i] = __builtin_amdgcn_s_memtime()
+#define STAMP(i) STAMP_AT(0, i)
+#define HSTAMP(i) STAMP_AT(8, i)
 #else
 #define STAMP(i)
+#define HSTAMP(i)
 #endif
 
 constexpr int WCK = 32;                    // channels per chunk
 constexpr int WP = WCK + 4;                // LDS floats per (pos, tile) row
 constexpr int WBUF = 16 * 32 * WP;         // floats per V buffer
 constexpr int WLDS_BYTES = 2 * WBUF * 4;   // 147456
-constexpr int WLDS_TOTAL = WLDS_BYTES + 48;  // + three tile-descriptor slots
+constexpr int WLDS_TOTAL = WLDS_BYTES + 64 + (WINO_STAMP ? 256 : 0);  // + three tile-descriptor slots (+ 32 stamps)
 constexpr int WTHREADS = 768;              // 8 MFMA waves + 4 helper waves
 #ifndef WINO_RING
 #define WINO_RING 4                        // U fragments in flight per MFMA wave (2 or 4)
+#endif
+#ifndef WINO_CPRIO
+#define WINO_CPRIO 1                       // wave priority of an MFMA wave inside an MFMA cluster
+#endif
+#ifndef WINO_HPRIO
+#define WINO_HPRIO 0                       // wave priority of the helper waves
 #endif
 
 __device__ __forceinline__ void wg_barrier() { __syncthreads(); }
@@ -86,6 +104,148 @@ __device__ __forceinline__ void wg_barrier() { __syncthreads(); }
 struct WinoTile {
   int item, tx, ty, n;  // work item (tile*nphase + phase) and its 16x8-pixel tile coordinates
 };
+
+// Output epilogue of one tile, run by the helper waves (a separate, non-inlined function: its 64
+// output registers get their own register allocation instead of competing with the kernel body).
+// The MFMA waves leave Y in the free V buffer with the V plane layout: plane p = 4*(2i+j) + g holds,
+// for output pixel (i,j) of every Winograd tile, channels 32g..32g+31 - so helper thread (pt, pq)
+// reads exactly the 16 float4 slots it will overwrite with the next V.
+// vmcnt retires the loads and stores of a wave in one order, so a load issued behind a store cannot
+// be consumed before the store is acknowledged (~2k cycles): all parameter loads and all arithmetic
+// come first and the 16 stores go out together at the end.
+struct WinoEpi {
+  float* out;
+  const float* bias;
+  const float* beta;
+  const float* gamma;
+  int H, W, Cout, act, nphase, s2d;
+};
+
+// pointers that arrive as function arguments are generic; these loads/stores are to global memory
+typedef __attribute__((address_space(1))) const char gchar;
+typedef __attribute__((address_space(1))) const floatx4 gfloatx4;
+__device__ __forceinline__ floatx4 gload4(const float* base, unsigned byte_off) {
+  return *(gfloatx4*)((gchar*)base + byte_off);
+}
+
+template <bool INV>
+__device__ __forceinline__ void wino_gdn_pairs(floatx4 (&y)[16], const WinoEpi& e, const unsigned (&cbyte)[4]) {
+  // bias + GDN/IGDN on pairs of channels (v_pk_* fp32 instructions); operation order of gdn_apply()
+  // all 12 parameter loads first: this wave runs alone on its SIMD, every exposed latency counts
+  floatx4 pb[4], pe[4], pg[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    pb[g] = gload4(e.bias, cbyte[g]);
+    pe[g] = gload4(e.beta, cbyte[g]);
+    pg[g] = gload4(e.gamma, cbyte[g]);
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const floatx4 cb = pb[g], ce = pe[g], cg = pg[g];
+#pragma unroll
+    for (int ij = 0; ij < 4; ++ij) {
+      const int p = ij * 4 + g;
+#pragma unroll
+      for (int q = 0; q < 4; q += 2) {
+        const floatx2 b2 = {cb[q], cb[q + 1]}, e2 = {ce[q], ce[q + 1]}, g2 = {cg[q], cg[q + 1]};
+        floatx2 v = {y[p][q], y[p][q + 1]};
+        v = v + b2;
+#if DSIC_EXACT_GDN
+        y[p][q] = gdn_apply(v[0], e2[0], g2[0], INV);
+        y[p][q + 1] = gdn_apply(v[1], e2[1], g2[1], INV);
+#else
+        const floatx2 s = e2 + g2 * (v * v);
+        floatx2 r = {__builtin_amdgcn_rsqf(s[0]), __builtin_amdgcn_rsqf(s[1])};
+        r = r * (1.5f - 0.5f * s * r * r);  // Newton step on 1/sqrt(s)
+        v = INV ? v * (s * r) : v * r;
+        y[p][q] = v[0];
+        y[p][q + 1] = v[1];
+#endif
+      }
+    }
+  }
+}
+
+static __device__ __noinline__ void wino_finish(WinoEpi e, WinoTile t, int yreg_floats, int ht) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  // the arguments arrive in VGPRs; all but ht are wave-uniform
+  e.out = (float*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)e.out >> 32)) << 32) |
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint64_t)e.out));
+  e.bias = (const float*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)e.bias >> 32)) << 32) |
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint64_t)e.bias));
+  e.beta = (const float*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)e.beta >> 32)) << 32) |
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint64_t)e.beta));
+  e.gamma = (const float*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)e.gamma >> 32)) << 32) |
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint64_t)e.gamma));
+  e.H = __builtin_amdgcn_readfirstlane(e.H);
+  e.W = __builtin_amdgcn_readfirstlane(e.W);
+  e.Cout = __builtin_amdgcn_readfirstlane(e.Cout);
+  e.act = __builtin_amdgcn_readfirstlane(e.act);
+  e.nphase = __builtin_amdgcn_readfirstlane(e.nphase);
+  e.s2d = __builtin_amdgcn_readfirstlane(e.s2d);
+  t.item = __builtin_amdgcn_readfirstlane(t.item);
+  t.tx = __builtin_amdgcn_readfirstlane(t.tx);
+  t.ty = __builtin_amdgcn_readfirstlane(t.ty);
+  t.n = __builtin_amdgcn_readfirstlane(t.n);
+  yreg_floats = __builtin_amdgcn_readfirstlane(yreg_floats);
+
+  const int pt = ht >> 3, pq = ht & 7;
+  const int ptx = pt & 7, pty = pt >> 3;
+  const float* yreg = lds + yreg_floats + pt * WP + 4 * pq;
+  floatx4 y[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p) y[p] = *(const floatx4*)(yreg + p * 32 * WP);
+  // per-channel parameters come from L1 every tile; channel groups beyond Cout read a clamped
+  // address and are never stored
+  unsigned cbyte[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int c0 = g * 32 + 4 * pq;
+    cbyte[g] = (unsigned)((c0 < e.Cout ? c0 : e.Cout - 4) * 4);
+  }
+  if (e.act == DSIC_ACT_GDN) {
+    wino_gdn_pairs<false>(y, e, cbyte);
+  } else if (e.act == DSIC_ACT_IGDN) {
+    wino_gdn_pairs<true>(y, e, cbyte);
+  } else {
+    const bool relu = e.act == DSIC_ACT_RELU;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const floatx4 pb = gload4(e.bias, cbyte[g]);
+#pragma unroll
+      for (int ij = 0; ij < 4; ++ij) {
+        floatx4 v = y[ij * 4 + g] + pb;
+        if (relu) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.f;
+        }
+        y[ij * 4 + g] = v;
+      }
+    }
+  }
+  // stores: uniform 64-bit image base + one 32-bit byte offset per output pixel (host checks the range)
+  const int phase = t.item & (e.nphase - 1);
+  const int ppy = phase >> 1, ppx = phase & 1;  // sub-pixel phase placement (ConvTranspose2d)
+  const int OH = e.nphase == 4 ? 2 * e.H : e.H, OW = e.nphase == 4 ? 2 * e.W : e.W;
+  __attribute__((address_space(1))) char* obase =
+      (__attribute__((address_space(1))) char*)(e.out + (size_t)t.n * OH * OW * e.Cout);
+#pragma unroll
+  for (int ij = 0; ij < 4; ++ij) {
+    const int oy = t.ty * 8 + 2 * pty + (ij >> 1);
+    const int ox = t.tx * 16 + 2 * ptx + (ij & 1);
+    if (oy < e.H && ox < e.W) {
+      const unsigned po =
+          (unsigned)(e.nphase == 4 ? ((2 * oy + ppy) * OW + (2 * ox + ppx)) * e.Cout
+                     : e.s2d       ? ((oy >> 1) * (e.W >> 1) + (ox >> 1)) * (4 * e.Cout) + ((oy & 1) * 2 + (ox & 1)) * e.Cout
+                                   : (oy * e.W + ox) * e.Cout) * 4u + 16u * pq;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (g * 32 + 4 * pq < e.Cout)
+          *(__attribute__((address_space(1))) floatx4*)(obase + (size_t)po + g * 128) = y[ij * 4 + g];
+    }
+  }
+}
+
 
 // ZSKIP: the launch has structurally zero Winograd positions (space-to-depth input or
 // ConvTranspose2d phases) whose MFMA clusters are skipped; plain 3x3 layers use ZSKIP = false
@@ -96,7 +256,10 @@ struct WinoTile {
 // vmcnt retires in order, so a wave that mixes HBM-latency input loads with the L2-latency U
 // stream stalls its MFMAs behind the slowest input load; separate waves have separate counters.
 // 12 waves = 3 per SIMD: the kernel must fit 168 VGPRs (128 of them accumulators).
-// Every wave executes the same barrier sequence: P0, P, then per tile B_0..B_{n-1}, E1, E2, E3.
+// The helpers also run the whole output epilogue (bias, GDN/IGDN/ReLU, 16-byte stores): the MFMA
+// waves only fold their accumulators into the 2x2 outputs inside the free V buffer and go on to
+// the next tile, so VALU and store work overlaps the next tile's MFMAs.
+// Every wave executes the same barrier sequence: P0, P, then per tile B_0..B_{n-1}, E1, E2.
 //
 // Tiles are handed out dynamically (first round = blockIdx.x, then a global ticket): a CU that is
 // slowed down - e.g. by co-resident waves of another stream - simply takes fewer tiles.  Helper
@@ -124,6 +287,7 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
     // =================================== helper waves ===========================================
     // thread = (Winograd tile pt, channel quad pq): the whole 4x4 pixel patch, 16 float4 loads
     // (8 adjacent lanes = 128 contiguous bytes), all 16 positions.
+    __builtin_amdgcn_s_setprio(WINO_HPRIO);
     const int ht = tid - 512;
     const int Cin = a.Cin;
     const int nchunks = Cin / WCK;
@@ -136,32 +300,50 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
       const intx4 v = {item, tile - row * a.tiles_x, row % a.tiles_y, row / a.tiles_y};
       *(intx4*)(slots + 4 * s) = v;
     };
-    auto produce = [&](const WinoTile& t, int chunk, float* vbuf) {
-      const bool border = t.ty == 0 || t.tx == 0 || t.ty * 8 + 9 > a.H || t.tx * 16 + 17 > a.W;  // uniform
+    // Input side, in three steps so that the loads of the next chunk can be put in flight before
+    // the helper waits at a barrier (a helper only gets issue slots while the MFMA waves idle: the
+    // SIMD issues one VALU-class instruction at a time and a pending MFMA holds the port):
+    //   aim(tile)    per-thread byte offsets of the 16 patch pixels inside the image (clamped to the
+    //                image; out-of-image pixels are zeroed through `okmask`), once per tile
+    //   issue(chunk) 16 float4 loads of the aimed tile's chunk
+    //   commit(vbuf) B^T d B and the 16 stores into the V buffer
+    struct Aim {
+      unsigned off[16];  // byte offsets of the 16 patch pixels inside the image (+ this thread's channel quad)
+      unsigned okmask;   // bit i*4+k: patch pixel (i,k) lies inside the image
+      const char* img;   // uniform
+    };
+    auto aim = [&](Aim& m, const WinoTile& t) {
       const int gy0 = t.ty * 8 + 2 * pty - 1, gx0 = t.tx * 16 + 2 * ptx - 1;
-      const char* base = (const char*)(a.in + (size_t)t.n * a.H * a.W * Cin + chunk * WCK);
-      floatx4 d[16];
+      m.img = (const char*)(a.in + (size_t)t.n * a.H * a.W * Cin);
+      m.okmask = 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        int gy = gy0 + i;
-        gy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);  // out-of-image pixels load a clamped address, zeroed below
+        const int gy = gy0 + i;
+        const bool yok = gy >= 0 && gy < a.H;
+        const int cy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          int gx = gx0 + k;
-          gx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
-          const unsigned off = (unsigned)(((gy * a.W + gx) * Cin + 4 * pq) * 4);
-          d[i * 4 + k] = *(const floatx4*)(base + off);
+          const int gx = gx0 + k;
+          const bool ok = yok && gx >= 0 && gx < a.W;
+          const int cx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+          m.off[i * 4 + k] = (unsigned)(((cy * a.W + cx) * Cin + 4 * pq) * 4);
+          m.okmask |= ok ? 1u << (i * 4 + k) : 0u;
         }
       }
-      if (border) {
+    };
+    auto issue = [&](floatx4 (&d)[16], const Aim& m, int chunk) {
+      int cbytes = chunk * (WCK * 4);
+      asm volatile("" : "+s"(cbytes));  // opaque: keeps "scalar base + 32-bit lane offset" from being hoisted as 16 64-bit addresses
+      const char* base = m.img + cbytes;
+#pragma unroll
+      for (int p = 0; p < 16; ++p) d[p] = *(const floatx4*)(base + m.off[p]);
+    };
+    auto commit = [&](floatx4 (&d)[16], const Aim& m, float* vbuf) {
+      if (__builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(m.okmask != 0xffffu) != 0)) {  // rare: border tile
         const floatx4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const bool yok = gy0 + i >= 0 && gy0 + i < a.H;
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (!(yok && gx0 + k >= 0 && gx0 + k < a.W)) d[i * 4 + k] = z;
-        }
+        for (int p = 0; p < 16; ++p)
+          if (!((m.okmask >> p) & 1u)) d[p] = z;
       }
       // columns, in place: (w0,w1,w2,w3) = (d0-d2, d1+d2, d2-d1, d1-d3)
 #pragma unroll
@@ -183,36 +365,95 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
         *(floatx4*)(dst + (3 * 4 + nu) * 32 * WP) = r1 - r3;
       }
     };
+    const WinoEpi epi = {a.out, a.bias, a.beta, a.gamma, a.H, a.W, a.Cout, a.act, a.nphase, a.s2d};
+    int tile_count = 0;
+    (void)tile_count;
     if (ht == 0) {
       post(0, (int)blockIdx.x);  // grid <= ntiles
       post(1, (int)(atomicAdd(a.ticket, 1ULL) + gridDim.x));
     }
     wg_barrier();  // P0: the first two descriptors are posted
     WinoTile cur = read_slot(0);
-    produce(cur, 0, lds);
+    {
+      Aim m;
+      floatx4 d[16];
+      aim(m, cur);
+      issue(d, m, 0);
+      commit(d, m, lds);
+    }
     wg_barrier();  // P
     int buf = 0, s_nxt = 1, s_wr = 2;
+    WinoTile prev = cur;
+    bool have_y = false;  // Y of tile `prev` waits in V[buf^1]
     while (cur.item < a.ntiles) {
       const WinoTile nxt = read_slot(s_nxt);
-      for (int chunk = 0; chunk < nchunks; ++chunk) {
+      const bool more = nxt.item < a.ntiles;
+      tile_count++;
+      floatx4 d[16];  // the patch in flight; dead across tiles
+      Aim m;          // likewise: re-aimed after the epilogue call, so nothing big lives across it
+      // chunk c: the MFMA waves consume V[buf]; the helpers fill V[buf^1] with target c =
+      // (cur, c+1), or (nxt, 0) for the last chunk.  Target 0 is loaded in chunk 0 itself (after the
+      // outputs of the previous tile have left, see finish_store); targets 1.. are put in flight
+      // one chunk early, before the barrier.
+      auto preissue = [&](int chunk) {  // loads of target chunk+1, if there is one
+        if (chunk + 2 < nchunks) {
+          issue(d, m, chunk + 2);
+        } else if (chunk + 2 == nchunks && more) {
+          aim(m, nxt);
+          issue(d, m, 0);
+        }
+      };
+      {  // chunk 0
         float* vnext = lds + (buf ^ 1) * WBUF;
-        if (chunk + 1 < nchunks)
-          produce(cur, chunk + 1, vnext);
-        else if (nxt.item < a.ntiles)
-          produce(nxt, 0, vnext);
-        if (chunk == 0 && ht == 0 && nxt.item < a.ntiles)
-          post(s_wr, (int)(atomicAdd(a.ticket, 1ULL) + gridDim.x));
+        HSTAMP(16);
+        // the ticket for the tile after next: fetched first, so that its return is the oldest entry
+        // of this wave's in-order vmcnt queue and nothing waits behind the input loads for it
+        int ticket = 0;
+        if (ht == 0 && more) ticket = (int)(atomicAdd(a.ticket, 1ULL) + gridDim.x);
+        if (have_y) {
+          HSTAMP(22);
+          wino_finish(epi, prev, (int)(vnext - lds), ht);
+          HSTAMP(23);
+        }
+        // (always aimed and loaded, so that the patch registers are defined on every path after the
+        //  call above; without a target the loads re-read this tile and are dropped)
+        const bool tgt0 = nchunks > 1 || more;
+        aim(m, nchunks == 1 && more ? nxt : cur);
+        issue(d, m, nchunks == 1 ? 0 : 1);
+        if (tgt0) commit(d, m, vnext);
+        if (ht == 0 && more) post(s_wr, ticket);
+        HSTAMP(30);
+        preissue(0);
+        HSTAMP(17);
+        wg_barrier();  // B_0
+        HSTAMP(18);
+        buf ^= 1;
+      }
+      for (int chunk = 1; chunk < nchunks; ++chunk) {
+        float* vnext = lds + (buf ^ 1) * WBUF;
+        if (chunk < 2) HSTAMP(16 + chunk * 3);
+        if (chunk + 1 < nchunks || more) commit(d, m, vnext);
+        if (chunk == 1) HSTAMP(28);
+        preissue(chunk);
+        if (chunk == 1) HSTAMP(29);
+        if (chunk < 2) HSTAMP(17 + chunk * 3);
         wg_barrier();  // B_chunk
+        if (chunk < 2) HSTAMP(18 + chunk * 3);
         buf ^= 1;
       }
       wg_barrier();  // E1
-      wg_barrier();  // E2
-      wg_barrier();  // E3: the MFMA waves' exchange/transpose area (= V[buf^1]) is free again
+      wg_barrier();  // E2: Y of this tile is complete in V[buf^1]
+      prev = cur;
+      have_y = true;
       cur = nxt;
       const int s_old = s_nxt;
       s_nxt = s_wr;
       s_wr = s_old == 0 ? 2 : s_old - 1;  // ring 0,1,2: cur slot of the finished tile becomes writable
     }
+    if (have_y) wino_finish(epi, prev, (buf ^ 1) * WBUF, ht);  // outputs of the last tile
+#if WINO_STAMP
+    if (wave == 8 && lane < 32) wino_stamps[blockIdx.x * 32 + lane] = ((long long*)(lds + 2 * WBUF + 16))[lane];
+#endif
     if (ht == 0) {  // last workgroup out re-arms the ticket for the next launch on this stream
       const unsigned long long done = atomicAdd(a.ticket + 1, 1ULL);
       if (done == (unsigned long long)gridDim.x - 1) {
@@ -260,15 +501,14 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
   for (int f = 0; f < R - 1; ++f) Bq[f] = fetch(f);
   int buf = 0, s_nxt = 1;
   while (cur.item < a.ntiles) {
-#pragma unroll
-    for (int p = 0; p < 8; ++p)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
     const WinoTile nxt = read_slot(s_nxt);
     const char* ubase_nxt =
         (const char*)(a.u + (size_t)((nxt.item < a.ntiles ? nxt.item : cur.item) & (a.nphase - 1)) * a.u_phase_stride);
     tile_count++;
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
+    // FIRST: chunk 0 of a tile starts every accumulator from a zero C operand (inline constant), so
+    // the 128 accumulator registers are never cleared by VALU moves
+    auto chunk_body = [&](auto first_tag, int chunk) {
+      constexpr bool FIRST = decltype(first_tag)::value;
       STAMP(chunk * 4 + 0);
       const bool last = chunk + 1 == nchunks;
       // Structurally zero Winograd positions: a 3-tap filter with a zero end tap has a zero
@@ -309,11 +549,17 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
         }
         const int p0 = it & 7;
         if (!ZSKIP || !is_zero(it)) {  // wave-uniform
-          __builtin_amdgcn_s_setprio(1);
+          if (WINO_CPRIO) __builtin_amdgcn_s_setprio(WINO_CPRIO);
 #pragma unroll
-          for (int s = 0; s < 4; ++s)
-            acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aq[it & 1][s], Bq[it % R][s], acc[p0], 0, 0, 0);
-          __builtin_amdgcn_s_setprio(0);
+          for (int s = 0; s < 4; ++s) {
+            const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aq[it & 1][s], Bq[it % R][s],
+                                                           FIRST && it < 8 && s == 0 ? zero : acc[p0], 0, 0, 0);
+          }
+          if (WINO_CPRIO) __builtin_amdgcn_s_setprio(0);
+        } else if (FIRST && it < 8) {  // a skipped position still has to read as zero in the fold
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[p0][e] = 0.f;
         }
       }
       STAMP(chunk * 4 + 1);
@@ -321,86 +567,48 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
       wg_barrier();  // B_chunk
       STAMP(chunk * 4 + 3);
       buf ^= 1;
-    }
+    };
+    chunk_body(std::true_type{}, 0);
+    for (int chunk = 1; chunk < nchunks; ++chunk) chunk_body(std::false_type{}, chunk);
 
-    // ---- inverse transform + epilogue ------------------------------------------------------
+
+    // ---- inverse transform ------------------------------------------------------------------
     // Wave (nt, ph) holds M[xi][nu] for xi in {2ph, 2ph+1}.  N[xi][j] = (M A)[xi][j]:
     //   N[.][0] = M0 + M1 + M2,  N[.][1] = M1 - M2 - M3.
     // Y[i][j] = (A^T N)[i][j]:  Y[0] = N0 + N1 + N2,  Y[1] = N1 - N2 - N3.
-    // ph=0 finishes row i=0 and needs N2 from ph=1; ph=1 finishes i=1 and needs N1 from ph=0.
+    //   ph=0: own = N0 + N1 (row 0), sends N1 to row 1;   ph=1: own = -(N2 + N3) (row 1), sends N2 to row 0.
+    // Each wave stores its own row's partial sum into the Y planes of the free V buffer, and after
+    // a barrier adds the term it owes to the other row in place (read, add, write: after the
+    // barrier exactly one lane touches each element): Y = own + received.
     STAMP(24);
-    // Register-lean form: keep only this wave's own partial sum per j and hand the other term
-    // to the partner straight away.
-    //   ph=0: own = N0 + N1, sends N1;   ph=1: own = -(N2 + N3), sends N2;   Y = own + received.
-    float* xch = lds + (buf ^ 1) * WBUF;  // 4 nt x 2 ph x 2 j x 16 e x 64 lanes = 16384 floats
-    floatx16 own[2];
     {
-      float* dst = xch + ((nt * 2 + ph) * 2) * 1024 + lane;
+      float* yreg = lds + (buf ^ 1) * WBUF;
+      // element e of this lane: Winograd tile (e&3) + 8*(e>>2) + 4h, channel 32nt + l31
+      float* yown = yreg + ((4 * (2 * ph) + nt) * 32 + 4 * h) * WP + l31;
+      float* yoth = yreg + ((4 * (2 * (ph ^ 1)) + nt) * 32 + 4 * h) * WP + l31;
+      floatx16 send[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const floatx16 na = j == 0 ? (acc[0] + acc[1]) + acc[2] : (acc[1] - acc[2]) - acc[3];  // local xi 0
         const floatx16 nb = j == 0 ? (acc[4] + acc[5]) + acc[6] : (acc[5] - acc[6]) - acc[7];  // local xi 1
-        own[j] = ph == 0 ? na + nb : -(na + nb);
+        const floatx16 own = ph == 0 ? na + nb : -(na + nb);
+        send[j] = ph == 0 ? nb : na;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) dst[j * 1024 + e * 64] = ph == 0 ? nb[e] : na[e];
+        for (int e = 0; e < 16; ++e) yown[(4 * j * 32 + (e & 3) + 8 * (e >> 2)) * WP] = own[e];
       }
-    }
-    wg_barrier();  // E1
-    floatx16 yv[2];
-    {
-      const float* src = xch + ((nt * 2 + (ph ^ 1)) * 2) * 1024 + lane;
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) yv[j][e] = own[j][e] + src[j * 1024 + e * 64];
-    }
-    wg_barrier();  // E2: exchange area becomes the per-wave transpose scratch
-    STAMP(25);
-
-    if (nvalid) {
-      const int phase = cur.item & (a.nphase - 1);
-      const int tx = cur.tx, ty = cur.ty, n = cur.n;
-      const int up = a.nphase == 4 ? 2 : 1, ppy = phase >> 1, ppx = phase & 1;  // sub-pixel phase placement
-      const int col = nt * 32 + l31;
-      const bool cok = col < a.Cout;
-      const float bias = cok ? a.bias[col] : 0.f;
-      float beta = 1.f, gamma = 0.f;
-      if (cok && (a.act == DSIC_ACT_GDN || a.act == DSIC_ACT_IGDN)) {
-        beta = a.beta[col];
-        gamma = a.gamma[col];
-      }
-      float* epi = xch + wave * (32 * 36);
+      wg_barrier();  // E1
+      STAMP(25);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
+        floatx16 got;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
-          epi[rr * 36 + l31] = wino_act(__fadd_rn(yv[j][e], bias), a.act, beta, gamma);
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        const int c4 = (lane & 7) * 4;
-        const int nn = nt * 32 + c4;
+        for (int e = 0; e < 16; ++e) got[e] = yoth[(4 * j * 32 + (e & 3) + 8 * (e >> 2)) * WP];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int rr = (lane >> 3) + 8 * i;  // Winograd tile index 0..31
-          const floatx4 v = *(const floatx4*)(epi + rr * 36 + c4);
-          const int oy = ty * 8 + 2 * (rr >> 3) + ph;
-          const int ox = tx * 16 + 2 * (rr & 7) + j;
-          if (oy < a.H && ox < a.W && nn < a.Cout) {
-            const size_t o = up == 2 ? (((size_t)n * (2 * a.H) + (2 * oy + ppy)) * (2 * a.W) + (2 * ox + ppx)) * a.Cout + nn
-                             : a.s2d ? (((size_t)n * (a.H >> 1) + (oy >> 1)) * (a.W >> 1) + (ox >> 1)) * (4 * a.Cout) +
-                                         ((oy & 1) * 2 + (ox & 1)) * a.Cout + nn
-                                   : (((size_t)n * a.H + oy) * a.W + ox) * a.Cout + nn;
-            *(floatx4*)(a.out + o) = v;
-          }
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
+        for (int e = 0; e < 16; ++e) yoth[(4 * j * 32 + (e & 3) + 8 * (e >> 2)) * WP] = got[e] + send[j][e];
       }
     }
     STAMP(26);
-    wg_barrier();  // E3: transpose patches done before the helpers reuse the area
+    wg_barrier();  // E2: the helpers take Y from here (activation + stores) and refill the buffer
     STAMP(27);
     cur = nxt;
     s_nxt = s_nxt == 2 ? 0 : s_nxt + 1;
@@ -559,6 +767,9 @@ static int wino_launch(WinoArgs& a, hipStream_t st) {
   a.tiles_x = ceil_div(W, 16); a.tiles_y = ceil_div(H, 8);
   const int64_t nt = (int64_t)a.tiles_x * a.tiles_y * B * a.nphase;
   DSIC_REQUIRE(nt < ((int64_t)1 << 31), "conv3x3_wino: too many tiles");
+  DSIC_REQUIRE((int64_t)H * W * a.Cin * 4 < ((int64_t)1 << 31) &&
+                   (int64_t)H * W * a.Cout * 4 * (a.nphase == 4 ? 4 : 1) < ((int64_t)1 << 31),
+               "conv3x3_wino: one image must stay below 2 GiB (32-bit offsets inside an image)");
   a.ntiles = (int)nt;
   static bool attr_set = false;
   if (!attr_set) {
