@@ -30,6 +30,9 @@
 #ifndef WINO_STAMP
 #define WINO_STAMP 0
 #endif
+#ifndef WINO_ABL
+#define WINO_ABL 0  // diagnostic ablations (wrong results): 1 no epilogue call, 2 no transform/V stores, 4 no input loads, 8 no fold
+#endif
 #ifndef WINO_STAMP_TILE
 #define WINO_STAMP_TILE 16  // which tile of a workgroup is stamped
 #endif
@@ -40,6 +43,33 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef int intx4 __attribute__((ext_vector_type(4)));
 typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+
+// a - b on two / four / sixteen floats with packed fp32 instructions.  The compiler packs fp32
+// additions (v_pk_add_f32) but leaves subtractions scalar; the negation is an operand modifier of
+// the same instruction, so a - b costs the same single issue slot.  Every VALU issue slot matters
+// here: a SIMD cannot issue VALU work of any wave while an MFMA is waiting for the matrix pipe.
+__device__ __forceinline__ floatx2 pk_sub(floatx2 a, floatx2 b) {
+  floatx2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ floatx4 sub4(floatx4 a, floatx4 b) {
+  const floatx2 lo = pk_sub(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1));
+  const floatx2 hi = pk_sub(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+__device__ __forceinline__ floatx16 sub16(floatx16 a, floatx16 b) {
+  floatx16 r;
+#pragma unroll
+  for (int i = 0; i < 16; i += 2) {
+    const floatx2 x = {a[i], a[i + 1]}, y = {b[i], b[i + 1]};
+    const floatx2 d = pk_sub(x, y);
+    r[i] = d[0];
+    r[i + 1] = d[1];
+  }
+  return r;
+}
 
 struct WinoArgs {
   const float* in;
@@ -303,66 +333,58 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
     // Input side, in three steps so that the loads of the next chunk can be put in flight before
     // the helper waits at a barrier (a helper only gets issue slots while the MFMA waves idle: the
     // SIMD issues one VALU-class instruction at a time and a pending MFMA holds the port):
-    //   aim(tile)    per-thread byte offsets of the 16 patch pixels inside the image (clamped to the
-    //                image; out-of-image pixels are zeroed through `okmask`), once per tile
+    //   aim(tile)    per-thread byte offsets of the 16 patch pixels inside the image, once per tile
     //   issue(chunk) 16 float4 loads of the aimed tile's chunk
     //   commit(vbuf) B^T d B and the 16 stores into the V buffer
+    // Input loads are raw buffer loads: descriptor (image base, image bytes) + one 32-bit byte offset
+    // per patch pixel + the chunk as scalar offset, i.e. no address arithmetic per load, and a pixel
+    // outside the image gets an offset beyond the descriptor's range, which the hardware reads as 0.
     struct Aim {
       unsigned off[16];  // byte offsets of the 16 patch pixels inside the image (+ this thread's channel quad)
-      unsigned okmask;   // bit i*4+k: patch pixel (i,k) lies inside the image
-      const char* img;   // uniform
+      __amdgpu_buffer_rsrc_t rsrc;  // uniform
     };
     auto aim = [&](Aim& m, const WinoTile& t) {
       const int gy0 = t.ty * 8 + 2 * pty - 1, gx0 = t.tx * 16 + 2 * ptx - 1;
-      m.img = (const char*)(a.in + (size_t)t.n * a.H * a.W * Cin);
-      m.okmask = 0;
+      m.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)t.n * a.H * a.W * Cin), 0,
+                                                 a.H * a.W * Cin * 4, 0x00020000);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int gy = gy0 + i;
         const bool yok = gy >= 0 && gy < a.H;
-        const int cy = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int gx = gx0 + k;
           const bool ok = yok && gx >= 0 && gx < a.W;
-          const int cx = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
-          m.off[i * 4 + k] = (unsigned)(((cy * a.W + cx) * Cin + 4 * pq) * 4);
-          m.okmask |= ok ? 1u << (i * 4 + k) : 0u;
+          m.off[i * 4 + k] = ok ? (unsigned)(((gy * a.W + gx) * Cin + 4 * pq) * 4) : 0x80000000u;
         }
       }
     };
     auto issue = [&](floatx4 (&d)[16], const Aim& m, int chunk) {
-      int cbytes = chunk * (WCK * 4);
-      asm volatile("" : "+s"(cbytes));  // opaque: keeps "scalar base + 32-bit lane offset" from being hoisted as 16 64-bit addresses
-      const char* base = m.img + cbytes;
+      if (WINO_ABL & 4) return;
 #pragma unroll
-      for (int p = 0; p < 16; ++p) d[p] = *(const floatx4*)(base + m.off[p]);
+      for (int p = 0; p < 16; ++p)
+        d[p] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(m.rsrc, m.off[p], chunk * (WCK * 4), 0));
     };
     auto commit = [&](floatx4 (&d)[16], const Aim& m, float* vbuf) {
-      if (__builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(m.okmask != 0xffffu) != 0)) {  // rare: border tile
-        const floatx4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int p = 0; p < 16; ++p)
-          if (!((m.okmask >> p) & 1u)) d[p] = z;
-      }
+      if (WINO_ABL & 2) return;
       // columns, in place: (w0,w1,w2,w3) = (d0-d2, d1+d2, d2-d1, d1-d3)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const floatx4 d0 = d[i * 4 + 0], d1 = d[i * 4 + 1], d2 = d[i * 4 + 2], d3 = d[i * 4 + 3];
-        d[i * 4 + 0] = d0 - d2;
+        d[i * 4 + 0] = sub4(d0, d2);
         d[i * 4 + 1] = d1 + d2;
-        d[i * 4 + 2] = d2 - d1;
-        d[i * 4 + 3] = d1 - d3;
+        d[i * 4 + 2] = sub4(d2, d1);
+        d[i * 4 + 3] = sub4(d1, d3);
       }
       // rows, straight to LDS: xi0 = r0-r2, xi1 = r1+r2, xi2 = r2-r1, xi3 = r1-r3
       float* dst = vbuf + vwrite;
 #pragma unroll
       for (int nu = 0; nu < 4; ++nu) {
         const floatx4 r0 = d[0 * 4 + nu], r1 = d[1 * 4 + nu], r2 = d[2 * 4 + nu], r3 = d[3 * 4 + nu];
-        *(floatx4*)(dst + (0 * 4 + nu) * 32 * WP) = r0 - r2;
+        *(floatx4*)(dst + (0 * 4 + nu) * 32 * WP) = sub4(r0, r2);
         *(floatx4*)(dst + (1 * 4 + nu) * 32 * WP) = r1 + r2;
-        *(floatx4*)(dst + (2 * 4 + nu) * 32 * WP) = r2 - r1;
-        *(floatx4*)(dst + (3 * 4 + nu) * 32 * WP) = r1 - r3;
+        *(floatx4*)(dst + (2 * 4 + nu) * 32 * WP) = sub4(r2, r1);
+        *(floatx4*)(dst + (3 * 4 + nu) * 32 * WP) = sub4(r1, r3);
       }
     };
     const WinoEpi epi = {a.out, a.bias, a.beta, a.gamma, a.H, a.W, a.Cout, a.act, a.nphase, a.s2d};
@@ -395,13 +417,17 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
       // (cur, c+1), or (nxt, 0) for the last chunk.  Target 0 is loaded in chunk 0 itself (after the
       // outputs of the previous tile have left, see finish_store); targets 1.. are put in flight
       // one chunk early, before the barrier.
-      auto preissue = [&](int chunk) {  // loads of target chunk+1, if there is one
-        if (chunk + 2 < nchunks) {
+      // Target chunk+1 = (cur, chunk+2) or (nxt, 0): re-aiming is VALU work and happens before the
+      // barrier; the 16 buffer loads need no VALU and are issued right behind the barrier, where
+      // they fly during the MFMA phase.
+      auto pre_aim = [&](int chunk) {
+        if (chunk + 2 == nchunks && more) aim(m, nxt);
+      };
+      auto post_issue = [&](int chunk) {
+        if (chunk + 2 < nchunks)
           issue(d, m, chunk + 2);
-        } else if (chunk + 2 == nchunks && more) {
-          aim(m, nxt);
+        else if (chunk + 2 == nchunks && more)
           issue(d, m, 0);
-        }
       };
       {  // chunk 0
         float* vnext = lds + (buf ^ 1) * WBUF;
@@ -412,7 +438,7 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
         if (ht == 0 && more) ticket = (int)(atomicAdd(a.ticket, 1ULL) + gridDim.x);
         if (have_y) {
           HSTAMP(22);
-          wino_finish(epi, prev, (int)(vnext - lds), ht);
+          if (!(WINO_ABL & 1)) wino_finish(epi, prev, (int)(vnext - lds), ht);
           HSTAMP(23);
         }
         // (always aimed and loaded, so that the patch registers are defined on every path after the
@@ -423,10 +449,11 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
         if (tgt0) commit(d, m, vnext);
         if (ht == 0 && more) post(s_wr, ticket);
         HSTAMP(30);
-        preissue(0);
+        pre_aim(0);
         HSTAMP(17);
         wg_barrier();  // B_0
         HSTAMP(18);
+        post_issue(0);
         buf ^= 1;
       }
       for (int chunk = 1; chunk < nchunks; ++chunk) {
@@ -434,11 +461,12 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
         if (chunk < 2) HSTAMP(16 + chunk * 3);
         if (chunk + 1 < nchunks || more) commit(d, m, vnext);
         if (chunk == 1) HSTAMP(28);
-        preissue(chunk);
+        pre_aim(chunk);
         if (chunk == 1) HSTAMP(29);
         if (chunk < 2) HSTAMP(17 + chunk * 3);
         wg_barrier();  // B_chunk
         if (chunk < 2) HSTAMP(18 + chunk * 3);
+        post_issue(chunk);
         buf ^= 1;
       }
       wg_barrier();  // E1
@@ -581,7 +609,9 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
     // a barrier adds the term it owes to the other row in place (read, add, write: after the
     // barrier exactly one lane touches each element): Y = own + received.
     STAMP(24);
-    {
+    if (WINO_ABL & 8) {
+      wg_barrier();
+    } else {
       float* yreg = lds + (buf ^ 1) * WBUF;
       // element e of this lane: Winograd tile (e&3) + 8*(e>>2) + 4h, channel 32nt + l31
       float* yown = yreg + ((4 * (2 * ph) + nt) * 32 + 4 * h) * WP + l31;
@@ -589,8 +619,8 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
       floatx16 send[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const floatx16 na = j == 0 ? (acc[0] + acc[1]) + acc[2] : (acc[1] - acc[2]) - acc[3];  // local xi 0
-        const floatx16 nb = j == 0 ? (acc[4] + acc[5]) + acc[6] : (acc[5] - acc[6]) - acc[7];  // local xi 1
+        const floatx16 na = j == 0 ? (acc[0] + acc[1]) + acc[2] : sub16(sub16(acc[1], acc[2]), acc[3]);  // local xi 0
+        const floatx16 nb = j == 0 ? (acc[4] + acc[5]) + acc[6] : sub16(sub16(acc[5], acc[6]), acc[7]);  // local xi 1
         const floatx16 own = ph == 0 ? na + nb : -(na + nb);
         send[j] = ph == 0 ? nb : na;
 #pragma unroll

@@ -1,11 +1,11 @@
 #!/bin/bash
-# A/B two builds of conv_wino.hip on the same box (diagnostic).
+# A/B builds of conv_wino.hip on the same box (diagnostic): one argument per build = its extra flags.
 set -e
 cd "$(dirname "$0")/.."
 for v in "$@"; do
   touch domain-specific-image-compression_amd/csrc/conv_wino.hip
   DSIC_EXTRA_FLAGS="$v" python domain-specific-image-compression_amd/build.py > /dev/null 2>&1
   for r in 1 2; do
-    echo "== $v run $r"; ONLY=g_a.4,g_a.8 python tools/conv_bench.py 2>&1 | grep g_a
+    echo "== [$v] run $r"; ONLY=${LAYERS:-g_a.2,g_a.4} python tools/conv_bench.py 2>&1 | grep g_a
   done
 done

@@ -16,6 +16,9 @@ __global__ __launch_bounds__(768) void k(long long* out, float* sink, int n_mfma
   lds[tid] = tid;
   __syncthreads();
   const long long t0 = __builtin_amdgcn_s_memtime();
+#ifdef HPRIO
+  if (wave >= 8) __builtin_amdgcn_s_setprio(HPRIO);
+#endif
   if (wave < 8) {
     if (run_mfma) {
       floatx16 acc[8];
