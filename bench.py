@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--channels", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernels", action="store_true", help="also print the per-kernel event timings to stderr")
     ap.add_argument("--coder-cus", type=int, default=0,
                     help="CUs reserved for the range coder's stream (0 = no CU masking)")
     ap.add_argument("--entropy", action="store_true",
@@ -186,6 +187,10 @@ def main():
 
     if rank == 0:
         agg = timer.summary()
+        if args.kernels:
+            for k, (c, t, f, x) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                print(f"{k:40s} {c:5d} launches {t / args.steps * 1e3:8.3f} ms/step  {f / t / 1e12:7.1f} TF/s algorithmic "
+                      f"{x / t / 1e12:7.1f} executed", file=sys.stderr)
         name, (cnt, secs, flops, exflops) = max(agg.items(), key=lambda kv: kv[1][1])
         achieved = flops / secs / 1e12
         conv_secs = sum(v[1] for v in agg.values())

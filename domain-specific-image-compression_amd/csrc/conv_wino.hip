@@ -33,6 +33,9 @@
 #ifndef WINO_ABL
 #define WINO_ABL 0  // diagnostic ablations (wrong results): 1 no epilogue call, 2 no transform/V stores, 4 no input loads, 8 no fold
 #endif
+#ifndef WINO_STAMP_CHUNK0
+#define WINO_STAMP_CHUNK0 0  // first of the four chunks whose MFMA phases are stamped
+#endif
 #ifndef WINO_STAMP_TILE
 #define WINO_STAMP_TILE 16  // which tile of a workgroup is stamped
 #endif
@@ -537,7 +540,7 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
     // the 128 accumulator registers are never cleared by VALU moves
     auto chunk_body = [&](auto first_tag, int chunk) {
       constexpr bool FIRST = decltype(first_tag)::value;
-      STAMP(chunk * 4 + 0);
+      if (chunk >= WINO_STAMP_CHUNK0 && chunk < WINO_STAMP_CHUNK0 + 4) STAMP((chunk - WINO_STAMP_CHUNK0) * 4 + 0);
       const bool last = chunk + 1 == nchunks;
       // Structurally zero Winograd positions: a 3-tap filter with a zero end tap has a zero
       // transform component (G (g0,g1,0)^T)[3] = 0, (G (0,g1,g2)^T)[0] = 0.  For the space-to-depth
@@ -590,10 +593,10 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
           for (int e = 0; e < 16; ++e) acc[p0][e] = 0.f;
         }
       }
-      STAMP(chunk * 4 + 1);
-      STAMP(chunk * 4 + 2);
+      if (chunk >= WINO_STAMP_CHUNK0 && chunk < WINO_STAMP_CHUNK0 + 4) STAMP((chunk - WINO_STAMP_CHUNK0) * 4 + 1);
+      if (chunk >= WINO_STAMP_CHUNK0 && chunk < WINO_STAMP_CHUNK0 + 4) STAMP((chunk - WINO_STAMP_CHUNK0) * 4 + 2);
       wg_barrier();  // B_chunk
-      STAMP(chunk * 4 + 3);
+      if (chunk >= WINO_STAMP_CHUNK0 && chunk < WINO_STAMP_CHUNK0 + 4) STAMP((chunk - WINO_STAMP_CHUNK0) * 4 + 3);
       buf ^= 1;
     };
     chunk_body(std::true_type{}, 0);

@@ -5,11 +5,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from dsic_amd import ops, lib
 B, h = 64, 128
-x = torch.randn(B, h, h, 128, device="cuda")
-w = ops.pack_wino_weight(torch.randn(128, 128, 3, 3, device="cuda") * 0.05)
+S2 = os.environ.get("LAYER", "") == "s2"   # LAYER=s2: a 5x5/s2 layer (3x3 over space-to-depth, 16 chunks, zero-position skipping)
+if S2:
+    x = torch.randn(B, h, h, 512, device="cuda")
+    w = ops.pack_wino_s2_weight(torch.randn(128, 128, 5, 5, device="cuda") * 0.05)
+else:
+    x = torch.randn(B, h, h, 128, device="cuda")
+    w = ops.pack_wino_weight(torch.randn(128, 128, 3, 3, device="cuda") * 0.05)
 bias = torch.randn(128, device="cuda"); beta = torch.rand(128, device="cuda") + 0.5; gamma = torch.rand(128, device="cuda") * 0.2
 for _ in range(3):
-    ops.conv3x3_wino_nhwc(x, w, bias, 128, ops.ACT_GDN, beta, gamma)
+    ops.conv3x3_wino_nhwc(x, w, bias, 128, ops.ACT_GDN, beta, gamma, s2d_in=S2)
 torch.cuda.synchronize()
 L = lib.load()
 buf = np.zeros(256 * 32, dtype=np.int64)
