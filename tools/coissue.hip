@@ -1,7 +1,14 @@
-// Microbenchmark (diagnostic): can VALU / LDS / VMEM instructions of one wave issue while two other
-// waves of the same SIMD keep the MFMA pipe busy with fp32 32x32x2 MFMAs?
+// Microbenchmark (diagnostic): can VALU / LDS / transcendental instructions of one wave issue while two
+// other waves of the same SIMD keep the MFMA pipe busy with fp32 32x32x2 MFMAs?
 // 768 threads: waves 0..7 run dependent MFMA clusters (two waves per SIMD), waves 8..11 run
-// `mode`: 0 = nothing, 1 = independent VALU fmas, 2 = LDS reads/writes, 3 = transcendental (rsq).
+// `mode`: 0 = nothing, 1 = independent VALU fmas, 2 = LDS reads, 3 = transcendental (rsq).
+//   hipcc --offload-arch=gfx950 -O3 [-DHPRIO=3] [-DPACE=n] -o tools/coissue tools/coissue.hip
+// Measured on MI355X (round 1): the MFMA waves run at exactly 64 cycles per MFMA whatever the third
+// wave does, and the third wave makes NO progress until they finish (helper time = MFMA time + its
+// own stand-alone time), with or without s_setprio 3 on it: a SIMD issues one VALU-class
+// instruction at a time and an MFMA waiting for the matrix pipe holds that port.  Pacing the MFMA
+// waves with s_nop (PACE) frees the port but costs more MFMA time than it gives.  Consequence for
+// conv_wino.hip: helper-wave VALU work is never free, it is paid in MFMA time 1:1.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
