@@ -110,7 +110,10 @@ __device__ long long wino_stamps[256 * 32];
 #define STAMP_AT(w, i) \
   if (WINO_STAMP && lane == 0 && wave == (w) && tile_count == WINO_STAMP_TILE) ((long long*)(lds + 2 * WBUF + 16))[i] = __builtin_amdgcn_s_memtime()
 #define STAMP(i) STAMP_AT(0, i)
-#define HSTAMP(i) STAMP_AT(8, i)
+#ifndef WINO_HSTAMP
+#define WINO_HSTAMP 1  // 0: no stamps in the helper waves (their stamp code perturbs what it measures)
+#endif
+#define HSTAMP(i) if (WINO_HSTAMP) STAMP_AT(8, i)
 #else
 #define STAMP(i)
 #define HSTAMP(i)
@@ -187,9 +190,13 @@ __device__ __forceinline__ void wino_gdn_pairs(floatx4 (&y)[16], const WinoEpi& 
         y[p][q] = gdn_apply(v[0], e2[0], g2[0], INV);
         y[p][q + 1] = gdn_apply(v[1], e2[1], g2[1], INV);
 #else
-        const floatx2 s = e2 + g2 * (v * v);
+        // same formula as gdn_apply(), with the two multiply-adds fused (v_pk_fma_f32): 8 (9) packed
+        // instructions + 2 v_rsq_f32 per channel pair
+        const floatx2 s = __builtin_elementwise_fma(g2, v * v, e2);
         floatx2 r = {__builtin_amdgcn_rsqf(s[0]), __builtin_amdgcn_rsqf(s[1])};
-        r = r * (1.5f - 0.5f * s * r * r);  // Newton step on 1/sqrt(s)
+        const floatx2 h = (-0.5f * s) * r;
+        const floatx2 c15 = {1.5f, 1.5f};
+        r = r * __builtin_elementwise_fma(h, r, c15);  // Newton step on 1/sqrt(s)
         v = INV ? v * (s * r) : v * r;
         y[p][q] = v[0];
         y[p][q + 1] = v[1];
