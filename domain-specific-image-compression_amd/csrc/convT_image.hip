@@ -1,0 +1,203 @@
+// Last synthesis layer: ConvTranspose2d(Cin, Cimg, 5, stride 2, padding 2, output_padding 1) from NHWC
+// features to the NCHW image (code/modelv2/layers.py:98, "deconv(N, out_ch)").
+//
+// With only 3 (or 4) output channels the layer is a skinny GEMM: N = 4 sub-pixel phases x Cimg
+// <= 16 columns, K = 9 taps x Cin.  Output pixel (2i+py, 2j+px) reads input (i-1+wr, j-1+wc) with
+//   g[wr][wc] = w[ci][c][py+4-2wr][px+4-2wc]  for wr >= py, wc >= px, else 0,
+// i.e. one 3x3 stride-1 convolution over the input grid whose columns are (phase, c).  It runs on
+// v_mfma_f32_16x16x4_f32 (N = 16: 12 of 16 columns useful for RGB) instead of the 32-column tiles of
+// conv_igemm.hip (12 of 32 useful): half the MFMA work for the same result, same exact-fp32 products.
+//
+// Workgroup = 256 threads = 4 waves on a 32x16-pixel tile of the input grid (64x32 output pixels).
+// Per 16-channel chunk the 34x18 window is staged in LDS (pixel stride 20 floats: conflict-free
+// ds_read_b128), next chunk's global loads in flight during the MFMAs.  Wave w owns rows 4w..4w+3:
+// 8 M tiles of 16 pixels.  MFMA operand map (lane l: r = l&15, q = l>>4): A[i=r][k=q], B[k=q][j=r],
+// D[i=4q+v][j=r]; k-step s of a chunk pairs channels {4q+s}, so both operands are one 16-byte read
+// per lane for four MFMAs.  Weights are packed [tap][Cin/16][col 16][16 ch] (73.7 KB for Cin=128,
+// L1/L2 resident).  Epilogue: + bias, interleave the phases through LDS, 16-byte NCHW stores.
+#include "common.h"
+
+namespace dsic {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int IT_W = 32, IT_H = 16;          // input-grid pixels per workgroup tile
+constexpr int IW = IT_W + 2, IH = IT_H + 2;  // staged window
+constexpr int ICK = 16, IP = ICK + 4;        // channels per chunk, LDS floats per window pixel
+constexpr int ISLOTS = (IH * IW * (ICK / 4) + 255) / 256;  // float4 staging slots per thread
+
+struct ImgArgs {
+  const float* in;
+  const float* w;  // packed [9][Cin/16][16][16]
+  const float* bias;
+  float* out;  // [B][Cimg][2H][2W]
+  int B, H, W, Cin, Cimg;
+  int tiles_x, tiles_y;
+};
+
+__global__ __launch_bounds__(256) void convT_image_kernel(const ImgArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[IH * IW * IP];  // 48 960 B; reused as the output tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  int bx = blockIdx.x;
+  const int tile_x = bx % a.tiles_x;
+  bx /= a.tiles_x;
+  const int tile_y = bx % a.tiles_y;
+  const int n = bx / a.tiles_y;
+  const int x0 = tile_x * IT_W, y0 = tile_y * IT_H;
+  const int Cin = a.Cin, C16 = Cin >> 4;
+
+  // staging slots of this thread: window pixel + channel quad -> global float offset (or -1) and LDS offset
+  const float* img = a.in + (size_t)n * a.H * a.W * Cin;
+  int goff[ISLOTS], loff[ISLOTS];
+#pragma unroll
+  for (int i = 0; i < ISLOTS; ++i) {
+    const int slot = tid + i * 256;
+    int g = -1, lo = -1;
+    if (slot < IH * IW * (ICK / 4)) {
+      const int pix = slot >> 2, cq = slot & 3;
+      const int wy = pix / IW, wx = pix % IW;
+      const int gy = y0 - 1 + wy, gx = x0 - 1 + wx;
+      lo = pix * IP + cq * 4;
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) g = (gy * a.W + gx) * Cin + cq * 4;
+    }
+    goff[i] = g;
+    loff[i] = lo;
+  }
+  floatx4 stage[ISLOTS];
+  auto load_chunk = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < ISLOTS; ++i) {
+      const floatx4 z = {0.f, 0.f, 0.f, 0.f};
+      stage[i] = goff[i] >= 0 ? *(const floatx4*)(img + goff[i] + chunk * ICK) : z;
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < ISLOTS; ++i)
+      if (loff[i] >= 0) *(floatx4*)(lds + loff[i]) = stage[i];
+  };
+
+  floatx4 acc[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) acc[m] = floatx4{0.f, 0.f, 0.f, 0.f};
+  // A fragment of M tile m (row m>>1 of this wave, x half m&1) at tap (0,0): + (wr*IW + wc)*IP per tap
+  const int abase = ((wave * 4) * IW + r) * IP + 4 * q;
+  const float* wl = a.w + r * 16 + 4 * q;  // + (tap*C16 + chunk)*256
+
+  load_chunk(0);
+  for (int chunk = 0; chunk < C16; ++chunk) {
+    __syncthreads();  // the previous chunk's window is no longer read
+    store_chunk();
+    __syncthreads();
+    if (chunk + 1 < C16) load_chunk(chunk + 1);  // in flight during the MFMAs below
+    floatx4 b = *(const floatx4*)(wl + (size_t)(0 * C16 + chunk) * 256);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int wr = tap / 3, wc = tap % 3;
+      const floatx4 bc = b;
+      if (tap + 1 < 9) b = *(const floatx4*)(wl + (size_t)((tap + 1) * C16 + chunk) * 256);
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const floatx4 av = *(const floatx4*)(lds + abase + (((m >> 1) + wr) * IW + (m & 1) * 16 + wc) * IP);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bc[s], acc[m], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: (phase, c) columns -> interleaved output pixels, through LDS --------------------
+  __syncthreads();  // window dead
+  const int Cimg = a.Cimg;
+  const int phase = r / Cimg, c = r - phase * Cimg;  // column r = phase*Cimg + c, valid if r < 4*Cimg
+  if (r < 4 * Cimg) {
+    const float bias = a.bias[c];
+    const int py = phase >> 1, px = phase & 1;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int yl = wave * 4 + (m >> 1);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int xl = (m & 1) * 16 + 4 * q + v;
+        lds[(c * (2 * IT_H) + 2 * yl + py) * (2 * IT_W) + 2 * xl + px] = __fadd_rn(acc[m][v], bias);
+      }
+    }
+  }
+  __syncthreads();
+  const int OH = 2 * a.H, OW = 2 * a.W;
+  const int oy0 = 2 * y0, ox0 = 2 * x0;
+  const bool vec = (OW & 3) == 0;
+  for (int idx = tid; idx < Cimg * (2 * IT_H) * (2 * IT_W / 4); idx += 256) {
+    const int x4 = idx % (2 * IT_W / 4);
+    const int oy = (idx / (2 * IT_W / 4)) % (2 * IT_H);
+    const int cc = idx / ((2 * IT_W / 4) * (2 * IT_H));
+    const int gy = oy0 + oy, gx = ox0 + 4 * x4;
+    if (gy >= OH || gx >= OW) continue;
+    const floatx4 v = *(const floatx4*)(lds + (cc * (2 * IT_H) + oy) * (2 * IT_W) + 4 * x4);
+    float* dst = a.out + (((size_t)n * Cimg + cc) * OH + gy) * OW + gx;
+    if (vec && gx + 3 < OW) {
+      *(floatx4*)dst = v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (gx + e < OW) dst[e] = v[e];
+    }
+  }
+}
+
+// w [Cin][Cimg][5][5] (nn.ConvTranspose2d layout) -> [9 taps][Cin/16][16 columns][16 channels]
+__global__ void pack_convT_image_weight_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cin,
+                                               int Cimg, int C16, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ch = i & 15;
+  int64_t rr = i >> 4;
+  const int col = rr & 15;
+  rr >>= 4;
+  const int c16 = rr % C16;
+  const int t = rr / C16;  // 0..8
+  const int wr = t / 3, wc = t % 3;
+  const int ci = c16 * 16 + ch;
+  float v = 0.f;
+  if (col < 4 * Cimg && ci < Cin) {
+    const int c = col % Cimg, ph = col / Cimg;
+    const int py = ph >> 1, px = ph & 1;
+    if (wr >= py && wc >= px) v = w[(((int64_t)ci * Cimg + c) * 5 + (py + 4 - 2 * wr)) * 5 + (px + 4 - 2 * wc)];
+  }
+  dst[i] = v;
+}
+
+}  // namespace dsic
+
+using namespace dsic;
+
+extern "C" int64_t dsic_convT_image_weight_floats(int Cin) { return (int64_t)9 * Cin * 16; }
+
+extern "C" int dsic_pack_convT_image_weight(const float* w, float* dst, int Cin, int Cimg, void* stream) {
+  DSIC_REQUIRE(w && dst, "pack_convT_image_weight: null pointer");
+  DSIC_REQUIRE(Cin > 0 && Cin % 16 == 0 && Cimg >= 1 && Cimg <= 4,
+               "pack_convT_image_weight: Cin=%d must be a multiple of 16 and Cimg=%d in [1,4]", Cin, Cimg);
+  const int64_t total = dsic_convT_image_weight_floats(Cin);
+  hipLaunchKernelGGL(pack_convT_image_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, w, dst, Cin, Cimg, Cin / 16, total);
+  return check_launch("pack_convT_image_weight");
+}
+
+extern "C" int dsic_conv_transpose2d_image(const float* in, const float* w_packed, const float* bias,
+                                           float* out_nchw, int B, int H, int W, int Cin, int Cimg,
+                                           void* stream) {
+  DSIC_REQUIRE(in && w_packed && bias && out_nchw, "convT_image: null pointer");
+  DSIC_REQUIRE(B > 0 && H > 0 && W > 0, "convT_image: empty tensor");
+  DSIC_REQUIRE(Cin > 0 && Cin % 16 == 0, "convT_image: Cin=%d must be a positive multiple of 16", Cin);
+  DSIC_REQUIRE(Cimg >= 1 && Cimg <= 4, "convT_image: Cimg=%d not in [1,4]", Cimg);
+  DSIC_REQUIRE((int64_t)H * W * Cin < (int64_t)1 << 29, "convT_image: image too large");
+  ImgArgs a{};
+  a.in = in; a.w = w_packed; a.bias = bias; a.out = out_nchw;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cimg = Cimg;
+  a.tiles_x = ceil_div(W, IT_W); a.tiles_y = ceil_div(H, IT_H);
+  const int64_t nblk = (int64_t)a.tiles_x * a.tiles_y * B;
+  DSIC_REQUIRE(nblk < ((int64_t)1 << 31), "convT_image: grid too large");
+  hipLaunchKernelGGL(convT_image_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("convT_image");
+}

@@ -43,8 +43,6 @@ namespace dsic {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-enum { OUT_NHWC = 0, OUT_IMAGE_NCHW = 1 };
-
 struct ConvArgs {
   const float* in;
   const float* w;
@@ -59,8 +57,6 @@ struct ConvArgs {
   int os;             // output stride: 1 conv, 2 convT phases
   int transposed;     // 1: four sub-pixel phases on blockIdx.y
   int act;
-  int out_mode;
-  int Cimg;           // OUT_IMAGE_NCHW: image channels (columns = 4*Cimg)
   int tiles_x, tiles_y;
   int dbg;            // diagnostic ablation bits (0 in production)
 };
@@ -266,7 +262,7 @@ __global__ __launch_bounds__(256, NTW == 2 ? 1 : 2) void conv_igemm_kernel(const
   for (int j = 0; j < NTW; ++j) {
     if (!nvalid[j]) continue;
     const int n = ntile[j] * 32 + l31;
-    if (a.out_mode == OUT_NHWC) {
+    {
       const bool nok = n < a.Cout;
       const float bias = nok ? a.bias[n] : 0.f;
       float beta = 1.f, gamma = 0.f;
@@ -315,27 +311,6 @@ __global__ __launch_bounds__(256, NTW == 2 ? 1 : 2) void conv_igemm_kernel(const
               const size_t o = (((size_t)ni * a.oH + (oy * a.os + py)) * a.oW + (ox * a.os + px)) * a.Cout + n;
               a.out[o] = apply_act(__fadd_rn(acc[m][j][e], bias), a.act, beta, gamma);
             }
-          }
-        }
-      }
-    } else {  // OUT_IMAGE_NCHW: column n = (py*2+px)*Cimg + c
-      if (n >= 4 * a.Cimg) continue;
-      const int c = n % a.Cimg;
-      const int ph = n / a.Cimg;
-      const int qy = ph >> 1, qx = ph & 1;
-      const float bias = a.bias[c];
-#pragma unroll
-      for (int m = 0; m < MTW; ++m) {
-        const int mt = NARROW ? wave : m;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int r = mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          const int ox = ox0 + r % TOW;
-          const int oy = oy0 + (r / TOW) % TOH;
-          const int ni = n0 + r / (TOW * TOH);
-          if (ni < a.B && oy < a.Ho && ox < a.Wo) {
-            const size_t o = (((size_t)ni * a.Cimg + c) * a.oH + (2 * oy + qy)) * a.oW + (2 * ox + qx);
-            a.out[o] = __fadd_rn(acc[m][j][e], bias);
           }
         }
       }
@@ -422,7 +397,7 @@ extern "C" int dsic_conv2d_nhwc(const float* in, const float* w_packed, const fl
   a.B = B; a.H = H; a.W = W; a.Cin = CinP;
   a.Ho = ceil_div(H, stride); a.Wo = ceil_div(W, stride);
   a.oH = a.Ho; a.oW = a.Wo; a.Cout = Cout; a.CoutP = round_up(Cout, 32);
-  a.os = 1; a.transposed = 0; a.act = act; a.out_mode = OUT_NHWC; a.Cimg = 0;
+  a.os = 1; a.transposed = 0; a.act = act;
   return run_conv(a, k, stride, 1, (hipStream_t)stream);
 }
 
@@ -442,22 +417,6 @@ extern "C" int dsic_conv_transpose2d_nhwc(const float* in, const float* w_packed
   a.in = in; a.w = w_packed; a.bias = bias; a.beta = beta; a.gamma = gamma; a.out = out;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin;
   a.Ho = H; a.Wo = W; a.oH = 2 * H; a.oW = 2 * W; a.Cout = Cout; a.CoutP = round_up(Cout, 32);
-  a.os = 2; a.transposed = 1; a.act = act; a.out_mode = OUT_NHWC; a.Cimg = 0;
+  a.os = 2; a.transposed = 1; a.act = act;
   return run_conv(a, 3, 1, 4, (hipStream_t)stream);
-}
-
-extern "C" int dsic_conv_transpose2d_image(const float* in, const float* w_packed,
-                                           const float* bias, float* out_nchw, int B, int H,
-                                           int W, int Cin, int Cimg, void* stream) {
-  DSIC_REQUIRE(in && w_packed && bias && out_nchw, "convT_image: null pointer");
-  DSIC_REQUIRE(B > 0 && H > 0 && W > 0, "convT_image: empty tensor");
-  DSIC_REQUIRE(Cin > 0 && Cin % 8 == 0, "convT_image: Cin=%d must be a positive multiple of 8", Cin);
-  DSIC_REQUIRE(Cimg >= 1 && Cimg <= 8, "convT_image: Cimg=%d not in [1,8]", Cimg);
-  DSIC_REQUIRE((int64_t)8 * H * W * Cin < (int64_t)1 << 31, "convT_image: image too large");
-  ConvArgs a{};
-  a.in = in; a.w = w_packed; a.bias = bias; a.beta = nullptr; a.gamma = nullptr; a.out = out_nchw;
-  a.B = B; a.H = H; a.W = W; a.Cin = Cin;
-  a.Ho = H; a.Wo = W; a.oH = 2 * H; a.oW = 2 * W; a.Cout = 4 * Cimg; a.CoutP = 32;
-  a.os = 1; a.transposed = 0; a.act = DSIC_ACT_NONE; a.out_mode = OUT_IMAGE_NCHW; a.Cimg = Cimg;
-  return run_conv(a, 3, 1, 1, (hipStream_t)stream);
 }

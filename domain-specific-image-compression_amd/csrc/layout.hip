@@ -49,31 +49,6 @@ __global__ void pack_convT_weight_kernel(const float* __restrict__ w, float* __r
   dst[i] = v;
 }
 
-__global__ void pack_convT_image_weight_kernel(const float* __restrict__ w,
-                                               float* __restrict__ dst, int Cin, int Cimg,
-                                               int Cin8, int64_t total) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int j = i & 7;
-  int64_t r = i >> 3;
-  const int n = r % 32;
-  r /= 32;
-  const int c8 = r % Cin8;
-  const int t = r / Cin8;  // 0..8
-  const int wr = t / 3, wc = t % 3;
-  const int c = c8 * 8 + j;
-  float v = 0.f;
-  if (n < 4 * Cimg && c < Cin) {
-    const int ci = n % Cimg, ph = n / Cimg;
-    const int py = ph >> 1, px = ph & 1;
-    if (wr >= py && wc >= px) {
-      const int ky = py + 4 - 2 * wr, kx = px + 4 - 2 * wc;
-      v = w[(((int64_t)c * Cimg + ci) * 5 + ky) * 5 + kx];
-    }
-  }
-  dst[i] = v;
-}
-
 __global__ void image_to_nhwc8_kernel(const float* __restrict__ x, float* __restrict__ dst, int C,
                                       int HW, int64_t total) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B*HW pixels
@@ -189,17 +164,6 @@ extern "C" int dsic_pack_convT_weight(const float* w, float* dst, int Cin, int C
   hipLaunchKernelGGL(pack_convT_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, w, dst, Cin, Cout, Cin8, CoutP, total);
   return check_launch("pack_convT_weight");
-}
-
-extern "C" int dsic_pack_convT_image_weight(const float* w, float* dst, int Cin, int Cimg,
-                                            void* stream) {
-  DSIC_REQUIRE(w && dst, "pack_convT_image_weight: null pointer");
-  DSIC_REQUIRE(Cin > 0 && Cin % 8 == 0 && Cimg >= 1 && Cimg <= 8, "pack_convT_image_weight: bad shape");
-  const int Cin8 = Cin / 8;
-  const int64_t total = (int64_t)9 * Cin8 * 32 * 8;
-  hipLaunchKernelGGL(pack_convT_image_weight_kernel, dim3((unsigned)((total + 255) / 256)),
-                     dim3(256), 0, (hipStream_t)stream, w, dst, Cin, Cimg, Cin8, total);
-  return check_launch("pack_convT_image_weight");
 }
 
 extern "C" int dsic_image_to_nhwc8(const float* x, float* dst, int B, int C, int H, int W,

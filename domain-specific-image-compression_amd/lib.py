@@ -24,6 +24,7 @@ SIGNATURES = {
     "dsic_packed_conv_weight_floats": (c_int64, [c_int, c_int, c_int]),
     "dsic_pack_conv_weight": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "dsic_pack_convT_weight": (c_int, [_P, _P, c_int, c_int, _P]),
+    "dsic_convT_image_weight_floats": (c_int64, [c_int]),
     "dsic_pack_convT_image_weight": (c_int, [_P, _P, c_int, c_int, _P]),
     "dsic_image_to_nhwc8": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "dsic_nhwc_to_nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -96,7 +96,9 @@ def pack_convT_image_weight(w: torch.Tensor) -> torch.Tensor:
     Cin, Cimg, k, k2 = w.shape
     if (k, k2) != (5, 5):
         raise ValueError("pack_convT_image_weight: kernel must be 5x5")
-    dst = torch.empty(9 * (Cin // 8) * 32 * 8, dtype=torch.float32, device=w.device)
+    if Cin % 16 or not 1 <= Cimg <= 4:
+        raise ValueError("pack_convT_image_weight: Cin must be a multiple of 16 and Cimg in [1,4]")
+    dst = torch.empty(_lib.load().dsic_convT_image_weight_floats(Cin), dtype=torch.float32, device=w.device)
     _lib.check(_lib.load().dsic_pack_convT_image_weight(_p(w), _p(dst), Cin, Cimg, _stream()),
                "pack_convT_image_weight")
     return dst
@@ -281,9 +283,10 @@ def conv_transpose2d_image(x, w_packed, bias, Cimg, out=None):
     if out is None:
         out = torch.empty((B, Cimg, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
     L = _lib.load()
-    _timed(_conv_kernel_name(3, 1, W, Cin, 32), 2.0 * B * H * W * Cimg * Cin * 25,
+    _timed("convT_image_kernel", 2.0 * B * H * W * Cimg * Cin * 25,
            lambda: _lib.check(L.dsic_conv_transpose2d_image(_p(x), _p(w_packed), _p(bias), _p(out), B, H, W,
-                                                            Cin, Cimg, _stream()), "conv_transpose2d_image"))
+                                                            Cin, Cimg, _stream()), "conv_transpose2d_image"),
+           exec_flops=2.0 * B * (-(-H // 16) * 16) * (-(-W // 32) * 32) * 16 * Cin * 9)
     return out
 
 

@@ -56,8 +56,10 @@ int dsic_pack_convT_weight(const float* w_iohw, float* dst, int Cin, int Cout,
                            void* stream);
 
 /* Last synthesis layer ConvTranspose2d(Cin,Cimg,5,2,2,1) (layers.py:97):
- * the four phases become the 4*Cimg output columns of ONE 3x3 stride-1
- * contraction over the input grid; packed [9][Cin/8][32][8]. */
+ * the four phases become the 4*Cimg <= 16 output columns of ONE 3x3 stride-1
+ * contraction over the input grid; packed [9][Cin/16][16][16] =
+ * dsic_convT_image_weight_floats(Cin) floats.  Cin % 16 == 0, Cimg in [1,4]. */
+int64_t dsic_convT_image_weight_floats(int Cin);
 int dsic_pack_convT_image_weight(const float* w_iohw, float* dst, int Cin,
                                  int Cimg, void* stream);
 

@@ -146,7 +146,8 @@ def test_conv_transpose_vs_oracle(ops, B, Cin, Cout, H, W, act):
     assert err <= _tol(ref, Cin * 9) * 4, (err, float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("B,Cin,Cimg,H,W", [(2, 128, 3, 16, 24), (1, 128, 4, 9, 5), (9, 128, 3, 3, 4)])
+@pytest.mark.parametrize("B,Cin,Cimg,H,W", [(2, 128, 3, 16, 24), (1, 128, 4, 9, 5), (9, 128, 3, 3, 4),
+                                             (1, 128, 3, 40, 70), (1, 64, 3, 17, 33), (2, 32, 1, 33, 65)])
 def test_conv_transpose_image_vs_oracle(ops, B, Cin, Cimg, H, W):
     x = _rand((B, Cin, H, W), 21, 2.0)
     w = _rand((Cin, Cimg, 5, 5), 22, (Cin * 6.25) ** -0.5 * 2)
