@@ -35,7 +35,10 @@ struct ImgArgs {
   int tiles_x, tiles_y;
 };
 
-__global__ __launch_bounds__(256) void convT_image_kernel(const ImgArgs a) {
+#ifndef IMG_WGS
+#define IMG_WGS 2  // workgroups per CU the register budget is set for (3 spills and is slower)
+#endif
+__global__ __launch_bounds__(256, IMG_WGS) void convT_image_kernel(const ImgArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[IH * IW * IP];  // 48 960 B; reused as the output tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

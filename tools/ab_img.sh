@@ -1,0 +1,11 @@
+#!/bin/bash
+# A/B builds of convT_image.hip on the same box (diagnostic): one argument per build = its extra flags.
+set -e
+cd "$(dirname "$0")/.."
+for v in "$@"; do
+  touch domain-specific-image-compression_amd/csrc/convT_image.hip
+  DSIC_EXTRA_FLAGS="$v" python domain-specific-image-compression_amd/build.py > /dev/null 2>&1
+  for r in 1 2; do
+    echo "== [$v] run $r"; ONLY=g_s.12 python tools/conv_bench.py 2>&1 | grep g_s
+  done
+done
