@@ -287,9 +287,13 @@ static __device__ __noinline__ void wino_finish(WinoEpi e, WinoTile t, int yreg_
 }
 
 
-// ZSKIP: the launch has structurally zero Winograd positions (space-to-depth input or
-// ConvTranspose2d phases) whose MFMA clusters are skipped; plain 3x3 layers use ZSKIP = false
-// and carry no test in the loop.
+// MODE 0: plain 3x3 layer.  MODE 1 (space-to-depth input) and MODE 2 (ConvTranspose2d phases) have
+// structurally zero Winograd positions whose MFMA clusters are skipped; MODE 0 carries no test in
+// the loop.  Steps run position-major (all four 8-channel groups of a position, then the next
+// position), MODE 2 from position 7 down: the positions that can be zero then sit mostly at the
+// end of a chunk, where the operand prefetch of the skipped steps runs into the chunk barrier
+// instead of stalling the next live step (a skipped step takes no time, so the U fragments of the
+// steps behind it have had no time to arrive).
 //
 // Wave specialisation.  Waves 0..7 ("MFMA waves") only read operands and issue MFMAs; waves 8..11
 // ("helpers", one per SIMD) load the NHWC input, apply B^T d B and fill the other LDS buffer.
@@ -306,7 +310,7 @@ static __device__ __noinline__ void wino_finish(WinoEpi e, WinoTile t, int yreg_
 // thread 0 fetches the ticket one tile ahead, splits it into (tx, ty, n) (the only integer
 // divisions of the kernel) and posts the descriptor in a 3-slot LDS ring: slot k%3 = the k-th
 // tile of this workgroup.
-template <bool ZSKIP>
+template <int MODE>
 __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -508,15 +512,21 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
   const int nt = wave & 3, ph = wave >> 2;
   const bool nvalid = nt * 32 < a.CoutP;
   const int nchunks = a.Cin / WCK;
-  // U stream: packed [pos][Cin/8][CoutP][8] floats; the fetch position advances by one position
-  // (step_p bytes) per fragment and wraps to the next 8-channel group after 8 of them.  Kept as
-  // one 32-bit lane offset against a uniform 64-bit base, so no per-fragment address is hoisted.
+  constexpr bool ZSKIP = MODE != 0;
+  constexpr int PDIR = MODE == 2 ? -1 : 1;  // step it = pi*4 + sub works on position p = (PDIR > 0 ? pi : 7 - pi)
+  // U stream: packed [pos][Cin/8][CoutP][8] floats; the fetch position advances by one 8-channel
+  // group (step_s bytes) per fragment, after four of them to the next position, after 32 to the
+  // first position of the next chunk.  Kept as one 32-bit lane offset against a uniform 64-bit
+  // base, so no per-fragment address is hoisted.
   const unsigned step_s = (unsigned)a.CoutP * 32u;             // bytes per 8-channel group
   const unsigned step_p = (unsigned)(a.Cin >> 3) * step_s;    // bytes per position
-  const unsigned step_wrap = step_s - 7u * step_p;             // p = 7 -> p = 0 of the next group
+  const unsigned step_pos = (unsigned)PDIR * step_p - 3u * step_s;    // (p, sub 3) -> (p + PDIR, sub 0)
+  const unsigned step_chunk = step_s - 7u * (unsigned)PDIR * step_p;  // (last p, sub 3) -> (first p, next chunk)
   const unsigned tile_wrap = (unsigned)(a.Cin >> 3) * step_s;  // all channel groups of a tile (= step_p)
-  const unsigned voff0 = (unsigned)ph * 8u * step_p + (unsigned)((((nvalid ? nt : 0) * 32 + l31) * 8 + 4 * h) * 4);
+  const unsigned voff0 = (unsigned)(ph * 8 + (PDIR > 0 ? 0 : 7)) * step_p +
+                         (unsigned)((((nvalid ? nt : 0) * 32 + l31) * 8 + 4 * h) * 4);
   const int aread = ((ph * 8) * 32 + l31) * WP + 4 * h;  // + p*32*WP + sub*8
+  auto pos_of = [](int it) { return PDIR > 0 ? it >> 2 : 7 - (it >> 2); };
   const int stamp_wave = 0;
   int tile_count = 0;
   (void)stamp_wave; (void)tile_count;
@@ -530,9 +540,9 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
   WinoTile cur = read_slot(0);
   const char* ubase = (const char*)(a.u + (size_t)(cur.item & (a.nphase - 1)) * a.u_phase_stride);  // of the fetch stream
   unsigned voff = voff0;  // fetch stream position
-  auto fetch = [&](int f) {  // fragment f = sub*8 + p of the stream; advances the position
+  auto fetch = [&](int f) {  // fragment of step f (mod 32) of the stream; advances the position
     const floatx4 v = *(const floatx4*)(ubase + voff);
-    voff += (f & 7) == 7 ? step_wrap : step_p;
+    voff += (f & 31) == 31 ? step_chunk : ((f & 3) == 3 ? step_pos : step_s);
     return v;
   };
 #pragma unroll
@@ -555,24 +565,25 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
       // vanish); for a ConvTranspose2d phase py=1 / px=1 lacks the first row / column (xi=0 /
       // nu=0 vanish).  Those MFMA clusters are skipped: 49 instead of 64 position-phase GEMMs.
       unsigned zero_xi = 4, zero_nu = 4;  // 4 = none
-      if (ZSKIP && a.s2d_in) {
+      if (MODE == 1) {
         const int blk = chunk / (nchunks >> 2);  // channel block (a,b) = (blk>>1, blk&1)
         if (blk >> 1) zero_xi = 3;
         if (blk & 1) zero_nu = 3;
-      } else if (ZSKIP && a.nphase == 4) {
+      } else if (MODE == 2) {
         const int phase = cur.item & 3;
         if (phase >> 1) zero_xi = 0;
         if (phase & 1) zero_nu = 0;
       }
-      auto is_zero = [&](int f) {
-        const unsigned xi = (unsigned)(ph * 2 + ((f & 7) >> 2)), nu = (unsigned)(f & 3);
+      auto is_zero = [&](int it) {
+        const int p = pos_of(it);
+        const unsigned xi = (unsigned)(ph * 2 + (p >> 2)), nu = (unsigned)(p & 3);
         return xi == zero_xi || nu == zero_nu;
       };
       const float* vb = lds + buf * WBUF + aread;
       floatx4 Aq[2];
-      Aq[0] = *(const floatx4*)(vb);
+      Aq[0] = *(const floatx4*)(vb + pos_of(0) * 32 * WP);
 #pragma unroll
-      for (int it = 0; it < 32; ++it) {  // it = sub*8 + p
+      for (int it = 0; it < 32; ++it) {  // it = pi*4 + sub
         {
           const int f = it + R - 1;  // U fragment to fetch now (continuous across chunks and tiles)
           if (f == 32 && last) {     // the stream moves on to the next tile: its phase's U, first group
@@ -582,20 +593,20 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
           Bq[f % R] = fetch(f);
         }
         if (it + 1 < 32) {
-          const int p1 = (it + 1) & 7, s1 = (it + 1) >> 3;
+          const int p1 = pos_of(it + 1), s1 = (it + 1) & 3;
           Aq[(it + 1) & 1] = *(const floatx4*)(vb + p1 * 32 * WP + s1 * 8);
         }
-        const int p0 = it & 7;
+        const int p0 = pos_of(it);
         if (!ZSKIP || !is_zero(it)) {  // wave-uniform
           if (WINO_CPRIO) __builtin_amdgcn_s_setprio(WINO_CPRIO);
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Aq[it & 1][s], Bq[it % R][s],
-                                                           FIRST && it < 8 && s == 0 ? zero : acc[p0], 0, 0, 0);
+                                                           FIRST && (it & 3) == 0 && s == 0 ? zero : acc[p0], 0, 0, 0);
           }
           if (WINO_CPRIO) __builtin_amdgcn_s_setprio(0);
-        } else if (FIRST && it < 8) {  // a skipped position still has to read as zero in the fold
+        } else if (FIRST && (it & 3) == 0) {  // a skipped position still has to read as zero in the fold
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[p0][e] = 0.f;
         }
@@ -813,10 +824,13 @@ static int wino_launch(WinoArgs& a, hipStream_t st) {
   a.ntiles = (int)nt;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wino_kernel<false>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wino_kernel<0>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, WLDS_TOTAL);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)conv_wino_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      e = hipFuncSetAttribute((const void*)conv_wino_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              WLDS_TOTAL);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)conv_wino_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               WLDS_TOTAL);
     if (e != hipSuccess) {
       set_error("conv3x3_wino: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -833,9 +847,11 @@ static int wino_launch(WinoArgs& a, hipStream_t st) {
     if (max_grid < 1 || max_grid > 1024) max_grid = 256;
   }
   const int grid = a.ntiles < max_grid ? a.ntiles : max_grid;
-  if (a.s2d_in || a.nphase == 4)
-    hipLaunchKernelGGL(conv_wino_kernel<true>, dim3(grid), dim3(WTHREADS), WLDS_TOTAL, st, a);
+  if (a.s2d_in)
+    hipLaunchKernelGGL(conv_wino_kernel<1>, dim3(grid), dim3(WTHREADS), WLDS_TOTAL, st, a);
+  else if (a.nphase == 4)
+    hipLaunchKernelGGL(conv_wino_kernel<2>, dim3(grid), dim3(WTHREADS), WLDS_TOTAL, st, a);
   else
-    hipLaunchKernelGGL(conv_wino_kernel<false>, dim3(grid), dim3(WTHREADS), WLDS_TOTAL, st, a);
+    hipLaunchKernelGGL(conv_wino_kernel<0>, dim3(grid), dim3(WTHREADS), WLDS_TOTAL, st, a);
   return check_launch("conv3x3_wino");
 }

@@ -202,7 +202,7 @@ def conv_transpose2d_wino_nhwc(x, u_packed4, bias, Cout, act=ACT_NONE, beta=None
         out = torch.empty((B, 2 * H, 2 * W, Cout), dtype=torch.float32, device=x.device)
     L = _lib.load()
     wino_tiles = 4 * B * (-(-H // 8)) * (-(-W // 16)) * 32
-    _timed("conv_wino_kernel<1>", 2.0 * B * H * W * Cout * Cin * 25,
+    _timed("conv_wino_kernel<2>", 2.0 * B * H * W * Cout * Cin * 25,
            lambda: _lib.check(L.dsic_conv_transpose2d_wino_nhwc(_p(x), _p(u_packed4), _p(bias), _p(beta), _p(gamma),
                                                                 _p(out), B, H, W, Cin, Cout, act, _p(_ticket(x.device)),
                                                                 _stream()),

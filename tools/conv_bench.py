@@ -48,6 +48,10 @@ for name, kind, ci, co, h, k, s in LAYERS:
         f = lambda: ops.conv2d_nhwc(x, w, bias, co, k, s, ops.ACT_GDN, beta, gamma)
         cin_real = 3 if ci == 8 else ci
         flops = 2.0 * B * (h // s) ** 2 * co * cin_real * k * k
+    elif kind == "convT" and os.environ.get("DSIC_WINOGRAD", "1") != "0":
+        w = ops.pack_wino_convT_weight(torch.randn(ci, co, 5, 5, device="cuda") * 0.05)
+        f = lambda: ops.conv_transpose2d_wino_nhwc(x, w, bias, co, ops.ACT_IGDN, beta, gamma)
+        flops = 2.0 * B * h * h * co * ci * 25
     elif kind == "convT":
         w = ops.pack_convT_weight(torch.randn(ci, co, 5, 5, device="cuda") * 0.05)
         f = lambda: ops.conv_transpose2d_nhwc(x, w, bias, co, ops.ACT_IGDN, beta, gamma)
