@@ -8,19 +8,18 @@
 // subtract and halve).  It is the same exact-fp32 MFMA instruction; only the
 // summation order differs from a direct convolution.
 //
-// Workgroup = 512 threads = 8 waves, persistent over output tiles of 16x8 pixels
-// (= 8x4 Winograd tiles = the 32 rows of one MFMA M tile).  The 16 Winograd
-// positions are 16 independent GEMMs  D_p[32 tiles][Cout] += V_p[32][Cin] U_p[Cin][Cout].
-// Wave w owns column tile nt = w&3 (32 output channels) and positions
-// 8*(w>>2) .. +7: 8 accumulators of 32x32 = 128 VGPRs, two waves per SIMD.
-// Per 32-channel chunk every thread loads 12 float4 of the NHWC input
-// (prefetched one chunk ahead, across tiles), transforms its (tile, 4 channels,
-// half of the positions) with 16 float4 add/subs and writes V into a
-// double-buffered LDS image [pos][tile][36]; U (transformed weights, packed
-// [pos][Cin/8][CoutP][8]) streams from L2 into registers.  Epilogue: the two
-// position halves exchange partial inverse transforms through LDS, each wave
-// finishes one output row parity, applies bias + activation and stores 16 bytes
-// per lane through the LDS transpose.
+// Persistent workgroups (one per CU) of 768 threads over output tiles of 16x8 pixels (= 8x4
+// Winograd tiles = the 32 rows of one MFMA M tile).  The 16 Winograd positions are 16 independent
+// GEMMs  D_p[32 tiles][Cout] += V_p[32][Cin] U_p[Cin][Cout].
+//   waves 0..7  (MFMA waves): wave w owns column tile nt = w&3 (32 output channels) and positions
+//               8*(w>>2) .. +7: 8 accumulators of 32x32 = 128 VGPRs, two such waves per SIMD.  Their
+//               loop reads V from LDS and U (transformed weights, packed [pos][Cin/8][CoutP][8], L2)
+//               and issues MFMAs, nothing else.
+//   waves 8..11 (helpers, one per SIMD): load the NHWC input (16 float4 per thread and 32-channel
+//               chunk, one chunk ahead), apply B^T d B and write V into the double-buffered LDS image
+//               [pos][tile][36]; after a tile they take the folded 2x2 outputs from the V buffer that
+//               has just been consumed, apply bias + activation and store 16 bytes per lane.
+// See DESIGN.md section 3 for the reasons (in-order vmcnt, VALU issue under MFMA) and the numbers.
 #include <stdlib.h>
 
 #include <type_traits>

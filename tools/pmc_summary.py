@@ -52,7 +52,7 @@ write = agg(os.path.join(G, "p3", "write_counter_collection.csv"), "WRITE_SIZE")
 out = {}
 detail = {}
 for k in sorted(set(fetch) | set(write)):
-    if not (k.startswith("conv_") or k in ("rate_kernel", "ssim_level_kernel", "range_encode_kernel",
+    if not (k.startswith("conv_") or k.startswith("convT_") or k in ("rate_kernel", "ssim_level_kernel", "range_encode_kernel",
                                                   "hyper_params_kernel", "image_to_nhwc8_kernel")):
         continue
     fn, fv = fetch.get(k, [0, 0.0])
