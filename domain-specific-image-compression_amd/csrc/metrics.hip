@@ -8,36 +8,41 @@
 // cs = (2 s_xy + C2)/(s_x + s_y + C2), ssim = (2 m_x m_y + C1)/(m_x^2+m_y^2+C1)*cs,
 // spatial means per (image, channel), 2x2 average pooling (padding = size%2,
 // zeros counted) between levels, prod_l relu(v_l)^w_l, mean over channels.
-// HBM-bound scans: one 16x16 output tile per workgroup, LDS-staged 26x26 halo
-// tiles, fixed-order fp64 partial sums (deterministic).
+// One 32x16 output tile per workgroup, LDS-staged 42x26 halo tile, fixed-order fp64 partial
+// sums (deterministic).
 #include "common.h"
 
 namespace dsic {
 
 #define WIN 11
-#define TS 16
-#define TIN (TS + WIN - 1)
+#define TSX 32                 // output tile: 32 x 16 per workgroup
+#define TSY 16
+#define TINX (TSX + WIN - 1)   // 42 x 26 input tile
+#define TINY (TSY + WIN - 1)
 
 struct GaussWin {
   float g[WIN];
 };
 
+// The scan is LDS-bound, not HBM-bound: every thread produces FOUR adjacent outputs along the
+// filter direction from 14 values held in registers (sliding window), 4x fewer LDS reads than one
+// output per thread.  Each output still sums its 11 taps in ascending order.
 __global__ __launch_bounds__(256) void ssim_level_kernel(const float* __restrict__ X,
                                                          const float* __restrict__ Y,
                                                          double* __restrict__ partial, int H, int W,
                                                          int tiles_x, int tiles_y, float C1, float C2,
                                                          int clamp_x, GaussWin gw) {
-  __shared__ float sx[TIN][TIN + 1], sy[TIN][TIN + 1];
-  __shared__ float tmp[5][TS][TIN + 1];
+  __shared__ float sx[TINY][TINX + 1], sy[TINY][TINX + 1];
+  __shared__ float tmp[5][TSY][TINX + 1];
   __shared__ double red[2][4];
   const int plane = blockIdx.z;
-  const int tx0 = blockIdx.x * TS, ty0 = blockIdx.y * TS;
+  const int tx0 = blockIdx.x * TSX, ty0 = blockIdx.y * TSY;
   const int Ho = H - (WIN - 1), Wo = W - (WIN - 1);
   const float* xp = X + (size_t)plane * H * W;
   const float* yp = Y + (size_t)plane * H * W;
   const int tid = threadIdx.x;
-  for (int i = tid; i < TIN * TIN; i += 256) {
-    const int r = i / TIN, c = i % TIN;
+  for (int i = tid; i < TINY * TINX; i += 256) {
+    const int r = i / TINX, c = i % TINX;
     const int gy = ty0 + r, gx = tx0 + c;
     float a = 0.f, b = 0.f;
     if (gy < H && gx < W) {
@@ -49,46 +54,68 @@ __global__ __launch_bounds__(256) void ssim_level_kernel(const float* __restrict
     sy[r][c] = b;
   }
   __syncthreads();
-  // pass 1: filter along H (rows) -> tmp[map][out_row][col]
-  for (int i = tid; i < TS * TIN; i += 256) {
-    const int r = i / TIN, c = i % TIN;
-    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f;
+  // pass 1: filter along H -> tmp[map][out_row][col]; thread = (column, group of 4 output rows)
+  if (tid < TINX * (TSY / 4)) {
+    const int c = tid % TINX, r0 = (tid / TINX) * 4;
+    float a[14], b[14], aa[14], bb[14], ab[14];
 #pragma unroll
-    for (int k = 0; k < WIN; ++k) {
-      const float a = sx[r + k][c], b = sy[r + k][c], g = gw.g[k];
-      m0 += g * a;
-      m1 += g * b;
-      m2 += g * (a * a);
-      m3 += g * (b * b);
-      m4 += g * (a * b);
+    for (int i = 0; i < 14; ++i) {
+      a[i] = sx[r0 + i][c];
+      b[i] = sy[r0 + i][c];
+      aa[i] = a[i] * a[i];
+      bb[i] = b[i] * b[i];
+      ab[i] = a[i] * b[i];
     }
-    tmp[0][r][c] = m0;
-    tmp[1][r][c] = m1;
-    tmp[2][r][c] = m2;
-    tmp[3][r][c] = m3;
-    tmp[4][r][c] = m4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f;
+#pragma unroll
+      for (int k = 0; k < WIN; ++k) {
+        const float g = gw.g[k];
+        m0 += g * a[j + k];
+        m1 += g * b[j + k];
+        m2 += g * aa[j + k];
+        m3 += g * bb[j + k];
+        m4 += g * ab[j + k];
+      }
+      tmp[0][r0 + j][c] = m0;
+      tmp[1][r0 + j][c] = m1;
+      tmp[2][r0 + j][c] = m2;
+      tmp[3][r0 + j][c] = m3;
+      tmp[4][r0 + j][c] = m4;
+    }
   }
   __syncthreads();
-  // pass 2: filter along W, one output pixel per thread
-  const int r = tid / TS, c = tid % TS;
-  float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f;
-#pragma unroll
-  for (int k = 0; k < WIN; ++k) {
-    const float g = gw.g[k];
-    m0 += g * tmp[0][r][c + k];
-    m1 += g * tmp[1][r][c + k];
-    m2 += g * tmp[2][r][c + k];
-    m3 += g * tmp[3][r][c + k];
-    m4 += g * tmp[4][r][c + k];
-  }
+  // pass 2: filter along W; thread = (output row, group of 4 output columns)
   double cs = 0.0, ss = 0.0;
-  if (ty0 + r < Ho && tx0 + c < Wo) {
-    const float mu1_sq = m0 * m0, mu2_sq = m1 * m1, mu12 = m0 * m1;
-    const float s1 = m2 - mu1_sq, s2 = m3 - mu2_sq, s12 = m4 - mu12;
-    const float csv = (2.f * s12 + C2) / (s1 + s2 + C2);
-    const float sv = ((2.f * mu12 + C1) / (mu1_sq + mu2_sq + C1)) * csv;
-    cs = (double)csv;
-    ss = (double)sv;
+  if (tid < TSY * (TSX / 4)) {
+    const int r = tid / (TSX / 4), c0 = (tid % (TSX / 4)) * 4;
+    float m[5][4];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      float t[14];
+#pragma unroll
+      for (int i = 0; i < 14; ++i) t[i] = tmp[q][r][c0 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < WIN; ++k) s += gw.g[k] * t[j + k];
+        m[q][j] = s;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (ty0 + r < Ho && tx0 + c0 + j < Wo) {
+        const float m0 = m[0][j], m1 = m[1][j];
+        const float mu1_sq = m0 * m0, mu2_sq = m1 * m1, mu12 = m0 * m1;
+        const float s1 = m[2][j] - mu1_sq, s2 = m[3][j] - mu2_sq, s12 = m[4][j] - mu12;
+        const float csv = (2.f * s12 + C2) / (s1 + s2 + C2);
+        const float sv = ((2.f * mu12 + C1) / (mu1_sq + mu2_sq + C1)) * csv;
+        cs += (double)csv;
+        ss += (double)sv;
+      }
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -197,7 +224,7 @@ extern "C" int dsic_ssim_level(const float* X, const float* Y, double* partial, 
   DSIC_REQUIRE(X && Y && partial && means, "ssim_level: null pointer");
   DSIC_REQUIRE(planes > 0 && H >= WIN && W >= WIN, "ssim_level: plane %dx%d smaller than the 11x11 window", H, W);
   const int Ho = H - (WIN - 1), Wo = W - (WIN - 1);
-  const int tx = ceil_div(Wo, TS), ty = ceil_div(Ho, TS);
+  const int tx = ceil_div(Wo, TSX), ty = ceil_div(Ho, TSY);
   DSIC_REQUIRE(planes <= 65535, "ssim_level: too many planes (%d)", planes);
   GaussWin gw;
   {
@@ -221,7 +248,7 @@ extern "C" int dsic_ssim_level(const float* X, const float* Y, double* partial, 
 
 extern "C" int64_t dsic_ssim_partial_doubles(int planes, int H, int W) {
   if (H < WIN || W < WIN) return 0;
-  return (int64_t)planes * ceil_div(H - WIN + 1, TS) * ceil_div(W - WIN + 1, TS) * 2;
+  return (int64_t)planes * ceil_div(H - WIN + 1, TSY) * ceil_div(W - WIN + 1, TSX) * 2;
 }
 
 extern "C" int dsic_avgpool2(const float* src, float* dst, int planes, int H, int W, int clamp,
