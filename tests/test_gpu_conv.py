@@ -198,7 +198,9 @@ WINO_CASES = [
     (1, 192, 128, 16, 16, "relu"),    # h_a.0: 6 chunks
     (3, 128, 128, 6, 10, "none"),     # fewer pixels than one tile
     (2, 64, 64, 24, 40, "gdn"),       # half-width column tiles idle
-    (70, 32, 128, 8, 16, "none"),     # more tiles than workgroups on a small box? (persistent loop)
+    (70, 32, 128, 8, 16, "none"),     # one tile per workgroup, single chunk
+    (300, 32, 64, 8, 16, "relu"),     # single-chunk layer, more tiles than workgroups (ticket loop)
+    (4, 128, 128, 96, 160, "gdn"),    # 480 tiles: every workgroup takes several through the ticket
 ]
 
 
@@ -229,7 +231,8 @@ def test_winograd_conv_vs_oracle(ops, B, Cin, Cout, H, W, act):
 
 
 @pytest.mark.parametrize("B,Cs,Cout,H,W,act", [(1, 128, 128, 32, 64, "gdn"), (2, 128, 128, 20, 36, "none"),
-                                               (1, 64, 64, 16, 16, "relu"), (3, 128, 128, 6, 10, "gdn")])
+                                               (1, 64, 64, 16, 16, "relu"), (3, 128, 128, 6, 10, "gdn"),
+                                               (2, 128, 128, 192, 224, "gdn")])
 def test_conv5x5_stride2_as_winograd_over_space_to_depth(ops, B, Cs, Cout, H, W, act):
     """conv(C,C,5,2) == 3x3 Winograd over the space-to-depth input with 4*C channels."""
     x = _rand((B, Cs, H, W), 51, 2.0)
@@ -267,7 +270,7 @@ def test_space_to_depth_epilogues(ops):
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W,act", [(2, 192, 128, 5, 7, "igdn"), (1, 128, 128, 16, 24, "igdn"),
                                                 (1, 128, 128, 9, 17, "relu"), (9, 128, 128, 2, 3, "none"),
-                                                (2, 128, 64, 32, 16, "none")])
+                                                (2, 128, 64, 32, 16, "none"), (3, 128, 128, 40, 72, "igdn")])
 def test_conv_transpose_winograd_vs_oracle(ops, B, Cin, Cout, H, W, act):
     x = _rand((B, Cin, H, W), 71, 2.0)
     w = _rand((Cin, Cout, 5, 5), 72, (Cin * 6.25) ** -0.5 * 2)
