@@ -50,6 +50,24 @@ __device__ __forceinline__ float gdn_apply(float v, float beta, float gamma, boo
   return inverse ? v * (s * r) : v * r;
 #endif
 }
+
+// The same on two values at once with packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32: 8 or 9
+// issue slots + 2 v_rsq_f32 per pair instead of 2 x 10); the two multiply-adds are fused.  Used where
+// the epilogue's VALU time competes with MFMA time.
+typedef float dsic_float2 __attribute__((ext_vector_type(2)));
+template <bool INV>
+__device__ __forceinline__ dsic_float2 gdn_pair(dsic_float2 v, dsic_float2 beta, dsic_float2 gamma) {
+#if DSIC_EXACT_GDN
+  return dsic_float2{gdn_apply(v[0], beta[0], gamma[0], INV), gdn_apply(v[1], beta[1], gamma[1], INV)};
+#else
+  const dsic_float2 s = __builtin_elementwise_fma(gamma, v * v, beta);
+  dsic_float2 r = {__builtin_amdgcn_rsqf(s[0]), __builtin_amdgcn_rsqf(s[1])};
+  const dsic_float2 h = (-0.5f * s) * r;
+  const dsic_float2 c15 = {1.5f, 1.5f};
+  r = r * __builtin_elementwise_fma(h, r, c15);  // Newton step on 1/sqrt(s)
+  return INV ? v * (s * r) : v * r;
+#endif
+}
 #endif
 
 }  // namespace dsic

@@ -100,15 +100,20 @@ __global__ __launch_bounds__(256, 2) void conv_first_kernel(
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
-      float v = __fadd_rn(acc[m][e], bs);
+    for (int e = 0; e < 16; e += 2) {  // pairs: packed fp32 arithmetic, this lane's column in both halves
+      dsic_float2 v = {acc[m][e], acc[m][e + 1]};
+      v = v + dsic_float2{bs, bs};
       if (act == DSIC_ACT_GDN) {
-        v = gdn_apply(v, be, ga, false);
+        v = gdn_pair<false>(v, dsic_float2{be, be}, dsic_float2{ga, ga});
       } else if (act == DSIC_ACT_RELU) {
-        v = v > 0.f ? v : 0.f;
+        v[0] = v[0] > 0.f ? v[0] : 0.f;
+        v[1] = v[1] > 0.f ? v[1] : 0.f;
       }
-      epi[rr * EPI_STRIDE + l31] = v;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int rr = ((e + k) & 3) + 8 * ((e + k) >> 2) + 4 * h;
+        epi[rr * EPI_STRIDE + l31] = v[k];
+      }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();

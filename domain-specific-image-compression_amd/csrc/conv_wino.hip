@@ -185,21 +185,9 @@ __device__ __forceinline__ void wino_gdn_pairs(floatx4 (&y)[16], const WinoEpi& 
         const floatx2 b2 = {cb[q], cb[q + 1]}, e2 = {ce[q], ce[q + 1]}, g2 = {cg[q], cg[q + 1]};
         floatx2 v = {y[p][q], y[p][q + 1]};
         v = v + b2;
-#if DSIC_EXACT_GDN
-        y[p][q] = gdn_apply(v[0], e2[0], g2[0], INV);
-        y[p][q + 1] = gdn_apply(v[1], e2[1], g2[1], INV);
-#else
-        // same formula as gdn_apply(), with the two multiply-adds fused (v_pk_fma_f32): 8 (9) packed
-        // instructions + 2 v_rsq_f32 per channel pair
-        const floatx2 s = __builtin_elementwise_fma(g2, v * v, e2);
-        floatx2 r = {__builtin_amdgcn_rsqf(s[0]), __builtin_amdgcn_rsqf(s[1])};
-        const floatx2 h = (-0.5f * s) * r;
-        const floatx2 c15 = {1.5f, 1.5f};
-        r = r * __builtin_elementwise_fma(h, r, c15);  // Newton step on 1/sqrt(s)
-        v = INV ? v * (s * r) : v * r;
+        v = gdn_pair<INV>(v, e2, g2);
         y[p][q] = v[0];
         y[p][q + 1] = v[1];
-#endif
       }
     }
   }
