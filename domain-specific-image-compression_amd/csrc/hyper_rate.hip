@@ -91,15 +91,22 @@ __global__ __launch_bounds__(256) void hyper_params_kernel(
 #define TWO_PI_F 6.283185307179586f
 #define PI_D 3.141592653589793
 
+#define RATE_SPLIT 16  // workgroups per image
+
 __global__ __launch_bounds__(256) void rate_kernel(
     const float* __restrict__ y, const float* __restrict__ z, const float* __restrict__ y_noisy,
     const float* __restrict__ z_noisy, const float* __restrict__ sigma, const float* __restrict__ nu,
     const float* __restrict__ z_log_sigma, float* __restrict__ y_hat, float* __restrict__ y_tilde,
     float* __restrict__ z_tilde, float* __restrict__ nll_y, float* __restrict__ nll_z,
-    double* __restrict__ sums, int HWy, int M, int HWz, int N, int per_element) {
+    double* __restrict__ part, int HWy, int M, int HWz, int N, int per_element) {
+  // grid (RATE_SPLIT, B): block (s, b) takes the s-th slice of image b's y elements; the last slice
+  // also takes z.  part[b][s][2] = this block's {sum nll_y, sum nll_z}; rate_reduce_kernel adds the
+  // slices in fixed order (deterministic, independent of the batch).
   __shared__ float s_sig[MAXM], s_nu[MAXM], s_logc[MAXM];
   __shared__ double scratch[4];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x;
+  const int per = ((HWy * M + RATE_SPLIT - 1) / RATE_SPLIT + 255) / 256 * 256;  // slice length, multiple of 256
+  const int i0 = slice * per, i1 = min(HWy * M, i0 + per);
   for (int c = tid; c < M && !per_element; c += 256) {
     // distributions.py:25-29; the channel constant is evaluated in fp64 and
     // rounded once (the reference evaluates it in fp32 per element).
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(256) void rate_kernel(
   __syncthreads();
   double acc = 0.0;
   const size_t ybase = (size_t)b * HWy * M;
-  for (int i = tid; i < HWy * M; i += 256) {  // i walks NHWC (coalesced reads)
+  for (int i = i0 + tid; i < i1; i += 256) {  // i walks NHWC (coalesced reads)
     const int p = i / M, c = i % M;
     const float v = y[ybase + i];
     const float r = rintf(v);  // torch.round: half to even
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(256) void rate_kernel(
   const double sy = block_sum(acc, scratch);
   acc = 0.0;
   const size_t zbase = (size_t)b * HWz * N;
-  for (int i = tid; i < HWz * N; i += 256) {
+  for (int i = tid; i < (slice == RATE_SPLIT - 1 ? HWz * N : 0); i += 256) {
     const int p = i / N, c = i % N;
     const float sg = fminf(fmaxf(expf(z_log_sigma[c]), 1e-3f), 1e3f);
     const float var = sg * sg;
@@ -158,9 +165,21 @@ __global__ __launch_bounds__(256) void rate_kernel(
   }
   const double sz = block_sum(acc, scratch);
   if (tid == 0) {
-    sums[2 * b] = sy;
-    sums[2 * b + 1] = sz;
+    part[((size_t)b * RATE_SPLIT + slice) * 2] = sy;
+    part[((size_t)b * RATE_SPLIT + slice) * 2 + 1] = sz;
   }
+}
+
+__global__ void rate_reduce_kernel(const double* __restrict__ part, double* __restrict__ sums, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double sy = 0.0, sz = 0.0;
+  for (int s = 0; s < RATE_SPLIT; ++s) {
+    sy += part[((size_t)b * RATE_SPLIT + s) * 2];
+    sz += part[((size_t)b * RATE_SPLIT + s) * 2 + 1];
+  }
+  sums[2 * b] = sy;
+  sums[2 * b + 1] = sz;
 }
 
 __global__ void gdn_nchw_kernel(const float* __restrict__ x, const float* __restrict__ beta,
@@ -283,17 +302,24 @@ extern "C" int dsic_rate(const float* y_nhwc, const float* z_nhwc, const float* 
                          const float* z_noisy_nhwc, const float* sigma, const float* nu,
                          const float* z_log_sigma, float* y_hat_nhwc, float* y_tilde_nchw,
                          float* z_tilde_nchw, float* nll_y_nchw, float* nll_z_nchw, double* sums,
-                         int B, int HWy, int M, int HWz, int N, int per_element, void* stream) {
+                         double* work, int B, int HWy, int M, int HWz, int N, int per_element,
+                         void* stream) {
   DSIC_REQUIRE(y_nhwc && z_nhwc && sigma && nu && z_log_sigma && y_hat_nhwc && y_tilde_nchw &&
-                   z_tilde_nchw && nll_y_nchw && nll_z_nchw && sums, "rate: null pointer");
+                   z_tilde_nchw && nll_y_nchw && nll_z_nchw && sums && work, "rate: null pointer");
   DSIC_REQUIRE(B > 0 && HWy > 0 && HWz > 0, "rate: empty tensor");
   DSIC_REQUIRE(M > 0 && M <= MAXM && N > 0, "rate: M=%d must be in [1,%d]", M, MAXM);
   DSIC_REQUIRE((int64_t)HWy * M < ((int64_t)1 << 31), "rate: latent too large");
-  hipLaunchKernelGGL(rate_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, y_nhwc, z_nhwc,
+  DSIC_REQUIRE(B <= 65535, "rate: B=%d exceeds the grid limit", B);
+  hipLaunchKernelGGL(rate_kernel, dim3(RATE_SPLIT, B), dim3(256), 0, (hipStream_t)stream, y_nhwc, z_nhwc,
                      y_noisy_nhwc, z_noisy_nhwc, sigma, nu, z_log_sigma, y_hat_nhwc, y_tilde_nchw,
-                     z_tilde_nchw, nll_y_nchw, nll_z_nchw, sums, HWy, M, HWz, N, per_element ? 1 : 0);
-  return check_launch("rate");
+                     z_tilde_nchw, nll_y_nchw, nll_z_nchw, work, HWy, M, HWz, N, per_element ? 1 : 0);
+  int rc = check_launch("rate");
+  if (rc) return rc;
+  hipLaunchKernelGGL(rate_reduce_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, work, sums, B);
+  return check_launch("rate_reduce");
 }
+
+extern "C" int64_t dsic_rate_workspace_doubles(int B) { return (int64_t)B * RATE_SPLIT * 2; }
 
 extern "C" int dsic_gdn_nchw(const float* x, const float* beta, const float* gamma, float* out, int B,
                              int C, int HW, int inverse, void* stream) {

@@ -47,7 +47,8 @@ SIGNATURES = {
     "dsic_conv_transpose2d_image": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "dsic_hyper_params": (c_int, [_P] * 13 + [c_int, c_int, c_int, c_int, ctypes.c_float,
                                      ctypes.c_float, _P]),
-    "dsic_rate": (c_int, [_P] * 13 + [c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "dsic_rate_workspace_doubles": (c_int64, [c_int]),
+    "dsic_rate": (c_int, [_P] * 14 + [c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "dsic_sigma_nu_spatial": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, ctypes.c_float, ctypes.c_float, _P]),
     "dsic_student_t_bits": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P]),
     "dsic_gaussian_bits": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),

@@ -336,12 +336,14 @@ def rate(y_nhwc, z_nhwc, sigma, nu, z_log_sigma, y_noisy=None, z_noisy=None):
     z_t = torch.empty((B, N, Hz, Wz), dtype=torch.float32, device=dev)
     nll_z = torch.empty_like(z_t)
     sums = torch.empty((B, 2), dtype=torch.float64, device=dev)
+    work = torch.empty(_lib.load().dsic_rate_workspace_doubles(B), dtype=torch.float64, device=dev)
     per_element = 1 if sigma.dim() == 4 else 0          # [B,M,Hy,Wy] (spatial_params) vs [B,M]
     sigma = _f32c(sigma, "rate")
     nu = _f32c(nu, "rate")
     _lib.check(_lib.load().dsic_rate(_p(y), _p(z), _p(y_noisy), _p(z_noisy), _p(sigma), _p(nu),
                                      _p(z_log_sigma), _p(y_hat), _p(y_t), _p(z_t), _p(nll_y), _p(nll_z),
-                                     _p(sums), B, Hy * Wy, M, Hz * Wz, N, per_element, _stream()), "rate")
+                                     _p(sums), _p(work), B, Hy * Wy, M, Hz * Wz, N, per_element, _stream()),
+               "rate")
     return {"y_hat_nhwc": y_hat, "y_tilde": y_t, "z_tilde": z_t, "nll_y": nll_y, "nll_z": nll_z,
             "sums": sums}
 

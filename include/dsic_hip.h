@@ -183,13 +183,16 @@ int dsic_hyper_params(const float* t_nhwc, const float* w1_sigma,
  * y_noisy/z_noisy (NHWC, may be NULL): when given they ARE y_tilde/z_tilde
  * (quant_mode="noise"), otherwise y_tilde = round(y).  Outputs: y_hat NHWC
  * (= round(y), the synthesis input), y_tilde/z_tilde/nll_y/nll_z in the
- * reference's NCHW, sums[B][2] = {sum nll_y, sum nll_z} as fp64. */
+ * reference's NCHW, sums[B][2] = {sum nll_y, sum nll_z} as fp64 (each image is
+ * summed by 16 workgroups whose partial sums are added in a fixed order).
+ * work: dsic_rate_workspace_doubles(B) doubles of device scratch. */
+int64_t dsic_rate_workspace_doubles(int B);
 int dsic_rate(const float* y_nhwc, const float* z_nhwc,
               const float* y_noisy_nhwc, const float* z_noisy_nhwc,
               const float* sigma, const float* nu, const float* z_log_sigma,
               float* y_hat_nhwc, float* y_tilde_nchw, float* z_tilde_nchw,
-              float* nll_y_nchw, float* nll_z_nchw, double* sums, int B,
-              int HWy, int M, int HWz, int N, int per_element, void* stream);
+              float* nll_y_nchw, float* nll_z_nchw, double* sums, double* work,
+              int B, int HWy, int M, int HWz, int N, int per_element, void* stream);
 
 /* spatial_params=True branch of model.py:49-51: the two 3x3 heads' NHWC outputs
  * [B,HW,M] -> sigma = exp(log_sigma), nu = clamp(exp(log_nu), min_nu, max_nu) as
