@@ -433,15 +433,16 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
       {  // chunk 0
         float* vnext = lds + (buf ^ 1) * WBUF;
         HSTAMP(16);
-        // the ticket for the tile after next: fetched first, so that its return is the oldest entry
-        // of this wave's in-order vmcnt queue and nothing waits behind the input loads for it
-        int ticket = 0;
-        if (ht == 0 && more) ticket = (int)(atomicAdd(a.ticket, 1ULL) + gridDim.x);
         if (have_y) {
           HSTAMP(22);
           if (!(WINO_ABL & 1)) wino_finish(epi, prev, (int)(vnext - lds), ht);
           HSTAMP(23);
         }
+        // the ticket for the tile after next: behind the epilogue call (a callee waits for every
+        // outstanding memory operation on entry) and ahead of the input loads, so that it is the
+        // oldest entry of this wave's in-order vmcnt queue and its latency hides behind theirs
+        int ticket = 0;
+        if (ht == 0 && more) ticket = (int)(atomicAdd(a.ticket, 1ULL) + gridDim.x);
         // (always aimed and loaded, so that the patch registers are defined on every path after the
         //  call above; without a target the loads re-read this tile and are dropped)
         const bool tgt0 = nchunks > 1 || more;
