@@ -45,7 +45,6 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef int intx4 __attribute__((ext_vector_type(4)));
 typedef float floatx2 __attribute__((ext_vector_type(2)));
-typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 
 // a - b on two / four / sixteen floats with packed fp32 instructions.  The compiler packs fp32
 // additions (v_pk_add_f32) but leaves subtractions scalar; the negation is an operand modifier of
@@ -93,15 +92,6 @@ struct WinoArgs {
   int tiles_x, tiles_y, ntiles;  // 16x8-pixel output tiles
 };
 
-__device__ __forceinline__ float wino_act(float v, int act, float beta, float gamma) {
-  if (act == DSIC_ACT_GDN || act == DSIC_ACT_IGDN) {
-    return gdn_apply(v, beta, gamma, act == DSIC_ACT_IGDN);
-  } else if (act == DSIC_ACT_RELU) {
-    return v > 0.f ? v : 0.f;
-  }
-  return v;
-}
-
 #if WINO_STAMP
 __device__ long long wino_stamps[256 * 32];
 // cycle stamps go to LDS (a global store would sit in the wave's in-order vmcnt queue and perturb
@@ -109,13 +99,8 @@ __device__ long long wino_stamps[256 * 32];
 #define STAMP_AT(w, i) \
   if (WINO_STAMP && lane == 0 && wave == (w) && tile_count == WINO_STAMP_TILE) ((long long*)(lds + 2 * WBUF + 16))[i] = __builtin_amdgcn_s_memtime()
 #define STAMP(i) STAMP_AT(0, i)
-#ifndef WINO_HSTAMP
-#define WINO_HSTAMP 1  // 0: no stamps in the helper waves (their stamp code perturbs what it measures)
-#endif
-#define HSTAMP(i) if (WINO_HSTAMP) STAMP_AT(8, i)
 #else
 #define STAMP(i)
-#define HSTAMP(i)
 #endif
 
 constexpr int WCK = 32;                    // channels per chunk
@@ -432,11 +417,8 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
       };
       {  // chunk 0
         float* vnext = lds + (buf ^ 1) * WBUF;
-        HSTAMP(16);
         if (have_y) {
-          HSTAMP(22);
           if (!(WINO_ABL & 1)) wino_finish(epi, prev, (int)(vnext - lds), ht);
-          HSTAMP(23);
         }
         // the ticket for the tile after next: behind the epilogue call (a callee waits for every
         // outstanding memory operation on entry) and ahead of the input loads, so that it is the
@@ -450,24 +432,16 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
         issue(d, m, nchunks == 1 ? 0 : 1);
         if (tgt0) commit(d, m, vnext);
         if (ht == 0 && more) post(s_wr, ticket);
-        HSTAMP(30);
         pre_aim(0);
-        HSTAMP(17);
         wg_barrier();  // B_0
-        HSTAMP(18);
         post_issue(0);
         buf ^= 1;
       }
       for (int chunk = 1; chunk < nchunks; ++chunk) {
         float* vnext = lds + (buf ^ 1) * WBUF;
-        if (chunk < 2) HSTAMP(16 + chunk * 3);
         if (chunk + 1 < nchunks || more) commit(d, m, vnext);
-        if (chunk == 1) HSTAMP(28);
         pre_aim(chunk);
-        if (chunk == 1) HSTAMP(29);
-        if (chunk < 2) HSTAMP(17 + chunk * 3);
         wg_barrier();  // B_chunk
-        if (chunk < 2) HSTAMP(18 + chunk * 3);
         post_issue(chunk);
         buf ^= 1;
       }

@@ -25,12 +25,5 @@ d = lambda a, b: np.median(s[:, b] - s[:, a])
 for c in range(4):
     print(f"chunk {c}: mfma {d(4*c, 4*c+1):8.0f}  barrier {d(4*c+2, 4*c+3):8.0f}")
     if c < 3: print(f"          gap to next chunk {d(4*c+3, 4*c+4):8.0f}")
-print(f"fold + own stores -> E1 {d(24, 25):8.0f}   ds_add {d(25, 26):8.0f}   E2 {d(26, 27):8.0f}")
+print(f"fold + own stores -> E1 {d(24, 25):8.0f}   partner row added {d(25, 26):8.0f}   E2 {d(26, 27):8.0f}")
 print(f"MFMA-wave tile total (chunk0 start -> after E2) {d(0, 27):8.0f}")
-print("helper wave 8 (same tile):")
-for c in range(2):
-    print(f"  chunk {c}: produce {d(16+3*c, 17+3*c):8.0f}  barrier wait {d(17+3*c, 18+3*c):8.0f}")
-print(f"  chunk 0: start->epilogue call {d(16, 22):6.0f}  epilogue {d(22, 23):6.0f}  aim+issue+commit+post {d(23, 30):6.0f}  preissue {d(30, 17):6.0f}")
-print(f"  chunk 1: commit {d(19, 28):6.0f}  preissue {d(28, 29):6.0f}  -> barrier {d(29, 20):6.0f}")
-print(f"  epilogue (Y read, activation, stores) {d(22, 23):8.0f}")
-print(f"  helper chunk0 start relative to MFMA chunk0 start {d(0, 16):8.0f}")
