@@ -484,9 +484,10 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
   const unsigned step_p = (unsigned)(a.Cin >> 3) * step_s;    // bytes per position
   const unsigned step_pos = (unsigned)PDIR * step_p - 3u * step_s;    // (p, sub 3) -> (p + PDIR, sub 0)
   const unsigned step_chunk = step_s - 7u * (unsigned)PDIR * step_p;  // (last p, sub 3) -> (first p, next chunk)
-  const unsigned tile_wrap = (unsigned)(a.Cin >> 3) * step_s;  // all channel groups of a tile (= step_p)
-  const unsigned voff0 = (unsigned)(ph * 8 + (PDIR > 0 ? 0 : 7)) * step_p +
-                         (unsigned)((((nvalid ? nt : 0) * 32 + l31) * 8 + 4 * h) * 4);
+  // The lane part of the address never changes; the stream position is a scalar (buffer load with
+  // SGPR offset), so the MFMA loop spends no VALU instruction on addressing.
+  const unsigned ulane = (unsigned)((((nvalid ? nt : 0) * 32 + l31) * 8 + 4 * h) * 4);
+  const unsigned soff0 = (unsigned)(ph * 8 + (PDIR > 0 ? 0 : 7)) * step_p;  // first fragment of a tile
   const int aread = ((ph * 8) * 32 + l31) * WP + 4 * h;  // + p*32*WP + sub*8
   auto pos_of = [](int it) { return PDIR > 0 ? it >> 2 : 7 - (it >> 2); };
   const int stamp_wave = 0;
@@ -500,11 +501,13 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
   wg_barrier();  // P0
   wg_barrier();  // P
   WinoTile cur = read_slot(0);
-  const char* ubase = (const char*)(a.u + (size_t)(cur.item & (a.nphase - 1)) * a.u_phase_stride);  // of the fetch stream
-  unsigned voff = voff0;  // fetch stream position
+  const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)a.u, 0, (int)(16u * step_p * (unsigned)a.nphase), 0x00020000);  // all phases' U (host checks < 2 GiB)
+  const unsigned phase_bytes = (unsigned)a.u_phase_stride * 4u;
+  unsigned soff = soff0 + (unsigned)(cur.item & (a.nphase - 1)) * phase_bytes;  // fetch stream position
   auto fetch = [&](int f) {  // fragment of step f (mod 32) of the stream; advances the position
-    const floatx4 v = *(const floatx4*)(ubase + voff);
-    voff += (f & 31) == 31 ? step_chunk : ((f & 3) == 3 ? step_pos : step_s);
+    const floatx4 v = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(urs, ulane, soff, 0));
+    soff += (f & 31) == 31 ? step_chunk : ((f & 3) == 3 ? step_pos : step_s);
     return v;
   };
 #pragma unroll
@@ -512,8 +515,7 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
   int buf = 0, s_nxt = 1;
   while (cur.item < a.ntiles) {
     const WinoTile nxt = read_slot(s_nxt);
-    const char* ubase_nxt =
-        (const char*)(a.u + (size_t)((nxt.item < a.ntiles ? nxt.item : cur.item) & (a.nphase - 1)) * a.u_phase_stride);
+    const unsigned soff_nxt = soff0 + (unsigned)((nxt.item < a.ntiles ? nxt.item : cur.item) & (a.nphase - 1)) * phase_bytes;
     tile_count++;
     // FIRST: chunk 0 of a tile starts every accumulator from a zero C operand (inline constant), so
     // the 128 accumulator registers are never cleared by VALU moves
@@ -548,10 +550,7 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
       for (int it = 0; it < 32; ++it) {  // it = pi*4 + sub
         {
           const int f = it + R - 1;  // U fragment to fetch now (continuous across chunks and tiles)
-          if (f == 32 && last) {     // the stream moves on to the next tile: its phase's U, first group
-            ubase = ubase_nxt;
-            voff -= tile_wrap;
-          }
+          if (f == 32 && last) soff = soff_nxt;  // the stream moves on to the next tile: its phase's U, first group
           Bq[f % R] = fetch(f);
         }
         if (it + 1 < 32) {
@@ -783,6 +782,8 @@ static int wino_launch(WinoArgs& a, hipStream_t st) {
   DSIC_REQUIRE((int64_t)H * W * a.Cin * 4 < ((int64_t)1 << 31) &&
                    (int64_t)H * W * a.Cout * 4 * (a.nphase == 4 ? 4 : 1) < ((int64_t)1 << 31),
                "conv3x3_wino: one image must stay below 2 GiB (32-bit offsets inside an image)");
+  DSIC_REQUIRE((int64_t)16 * (a.Cin / 8) * a.CoutP * 8 * 4 * a.nphase < ((int64_t)1 << 31),
+               "conv3x3_wino: transformed weights must stay below 2 GiB");
   a.ntiles = (int)nt;
   static bool attr_set = false;
   if (!attr_set) {
