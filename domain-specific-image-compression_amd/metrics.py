@@ -60,13 +60,25 @@ def _levels(X, Y, n_levels, data_range, clamp_x):
     return means
 
 
+_weight_cache = {}
+
+
+def _weights_on(device, weights):
+    key = (str(device), weights)
+    w = _weight_cache.get(key)
+    if w is None:
+        w = torch.tensor(list(weights), dtype=torch.float32, device=device)
+        _weight_cache[key] = w
+    return w
+
+
 def ms_ssim_per_image(X, Y, data_range=1.0, weights=(0.3, 0.5, 0.2), clamp_x=False):
     """Per-image MS-SSIM [B] (pytorch_msssim.ms_ssim(..., size_average=False))."""
     B, C, H, W = X.shape
     # pytorch-msssim 1.0.0 asserts this whatever len(weights) is (SURVEY.md §6)
     assert min(H, W) > (11 - 1) * 2 ** 4, \
         "Image size should be larger than %d due to the 4 downsamplings in ms-ssim" % ((11 - 1) * 2 ** 4)
-    w = torch.tensor(list(weights), dtype=torch.float32, device=X.device)
+    w = _weights_on(X.device, tuple(float(v) for v in weights))   # cached: a host->device copy per call stalls the stream
     means = _levels(X, Y, len(weights), data_range, clamp_x)
     out = torch.empty(B, dtype=torch.float32, device=X.device)
     _lib.check(_lib.load().dsic_msssim_finalize(_p(means), _p(w), _p(out), len(weights), B, C, 1, _stream()),
