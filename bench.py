@@ -199,6 +199,11 @@ def main():
         if os.path.exists(pmc_path):
             with open(pmc_path) as f:
                 pmc = json.load(f).get(name)
+        mfma_pmc = None
+        mfma_path = os.path.join(ROOT, "profiles", "round1_mfma_util.json")
+        if os.path.exists(mfma_path):
+            with open(mfma_path) as f:
+                mfma_pmc = (json.load(f).get(name) or {}).get("mfma_util")
         res = {
             "metric": "256x256 satellite patches encoded/s per GPU; bpp + MS-SSIM vs reference",
             "value": value,
@@ -239,6 +244,9 @@ def main():
                 # Winograd kernel executes 2.25x (3x3) / 1.56x (5x5 s2) fewer on the MFMA pipe:
                 "executed": exflops / secs / 1e12,
                 "executed_frac": exflops / secs / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x SIMDs) of the same kernel from a separate
+                # rocprofv3 --pmc pass (profiles/round1_mfma_util.json): per clock actually run, not per 2.4 GHz
+                "mfma_busy_pmc": mfma_pmc,
                 "all_conv_tflops": sum(v[2] for v in agg.values()) / conv_secs / 1e12,
                 "all_conv_executed_tflops": sum(v[3] for v in agg.values()) / conv_secs / 1e12,
                 "conv_share_of_step": conv_secs / elapsed,
