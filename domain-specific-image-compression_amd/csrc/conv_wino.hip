@@ -505,8 +505,12 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
       (void*)a.u, 0, (int)(16u * step_p * (unsigned)a.nphase), 0x00020000);  // all phases' U (host checks < 2 GiB)
   const unsigned phase_bytes = (unsigned)a.u_phase_stride * 4u;
   unsigned soff = soff0 + (unsigned)(cur.item & (a.nphase - 1)) * phase_bytes;  // fetch stream position
-  auto fetch = [&](int f) {  // fragment of step f (mod 32) of the stream; advances the position
-    const floatx4 v = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(urs, ulane, soff, 0));
+  // skip: the step is a structurally zero position of this chunk - its MFMAs will not run, so the
+  // load is pointed at the tile's first fragment (an L1/L2 hit) instead of pulling a line of zeros
+  // through L2; the stream position advances all the same.
+  auto fetch = [&](int f, bool skip = false) {  // fragment of step f (mod 32) of the stream
+    const unsigned so = skip ? soff0 : soff;
+    const floatx4 v = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(urs, ulane, so, 0));
     soff += (f & 31) == 31 ? step_chunk : ((f & 3) == 3 ? step_pos : step_s);
     return v;
   };
@@ -551,7 +555,8 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
         {
           const int f = it + R - 1;  // U fragment to fetch now (continuous across chunks and tiles)
           if (f == 32 && last) soff = soff_nxt;  // the stream moves on to the next tile: its phase's U, first group
-          Bq[f % R] = fetch(f);
+          // (the first R-1 steps of the next chunk are never zero positions: position 0, or 7 in MODE 2)
+          Bq[f % R] = fetch(f, ZSKIP && f < 32 && is_zero(f));
         }
         if (it + 1 < 32) {
           const int p1 = pos_of(it + 1), s1 = (it + 1) & 3;
