@@ -17,8 +17,9 @@
 //               and issues MFMAs, nothing else.
 //   waves 8..11 (helpers, one per SIMD): load the NHWC input (16 float4 per thread and 32-channel
 //               chunk, one chunk ahead), apply B^T d B and write V into the double-buffered LDS image
-//               [pos][tile][36]; after a tile they take the folded 2x2 outputs from the V buffer that
-//               has just been consumed, apply bias + activation and store 16 bytes per lane.
+//               [pos][tile][36]; after a tile they copy the finished 2x2 outputs (folded and activated
+//               by the MFMA waves inside the V buffer that has just been consumed) to HBM, 16 bytes
+//               per lane.
 // See DESIGN.md section 3 for the reasons (in-order vmcnt, VALU issue under MFMA) and the numbers.
 #include <stdlib.h>
 
@@ -125,140 +126,6 @@ struct WinoTile {
   int item, tx, ty, n;  // work item (tile*nphase + phase) and its 16x8-pixel tile coordinates
 };
 
-// Output epilogue of one tile, run by the helper waves (a separate, non-inlined function: its 64
-// output registers get their own register allocation instead of competing with the kernel body).
-// The MFMA waves leave Y in the free V buffer with the V plane layout: plane p = 4*(2i+j) + g holds,
-// for output pixel (i,j) of every Winograd tile, channels 32g..32g+31 - so helper thread (pt, pq)
-// reads exactly the 16 float4 slots it will overwrite with the next V.
-// vmcnt retires the loads and stores of a wave in one order, so a load issued behind a store cannot
-// be consumed before the store is acknowledged (~2k cycles): all parameter loads and all arithmetic
-// come first and the 16 stores go out together at the end.
-struct WinoEpi {
-  float* out;
-  const float* bias;
-  const float* beta;
-  const float* gamma;
-  int H, W, Cout, act, nphase, s2d;
-};
-
-// pointers that arrive as function arguments are generic; these loads/stores are to global memory
-typedef __attribute__((address_space(1))) const char gchar;
-typedef __attribute__((address_space(1))) const floatx4 gfloatx4;
-__device__ __forceinline__ floatx4 gload4(const float* base, unsigned byte_off) {
-  return *(gfloatx4*)((gchar*)base + byte_off);
-}
-
-template <bool INV>
-__device__ __forceinline__ void wino_gdn_pairs(floatx4 (&y)[16], const WinoEpi& e, const unsigned (&cbyte)[4]) {
-  // bias + GDN/IGDN on pairs of channels (v_pk_* fp32 instructions); operation order of gdn_apply()
-  // all 12 parameter loads first: this wave runs alone on its SIMD, every exposed latency counts
-  floatx4 pb[4], pe[4], pg[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    pb[g] = gload4(e.bias, cbyte[g]);
-    pe[g] = gload4(e.beta, cbyte[g]);
-    pg[g] = gload4(e.gamma, cbyte[g]);
-  }
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const floatx4 cb = pb[g], ce = pe[g], cg = pg[g];
-#pragma unroll
-    for (int ij = 0; ij < 4; ++ij) {
-      const int p = ij * 4 + g;
-#pragma unroll
-      for (int q = 0; q < 4; q += 2) {
-        const floatx2 b2 = {cb[q], cb[q + 1]}, e2 = {ce[q], ce[q + 1]}, g2 = {cg[q], cg[q + 1]};
-        floatx2 v = {y[p][q], y[p][q + 1]};
-        v = v + b2;
-        v = gdn_pair<INV>(v, e2, g2);
-        y[p][q] = v[0];
-        y[p][q + 1] = v[1];
-      }
-    }
-  }
-}
-
-static __device__ __noinline__ void wino_finish(WinoEpi e, WinoTile t, int yreg_floats, int ht) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  // the arguments arrive in VGPRs; all but ht are wave-uniform
-  e.out = (float*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)e.out >> 32)) << 32) |
-                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint64_t)e.out));
-  e.bias = (const float*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)e.bias >> 32)) << 32) |
-                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint64_t)e.bias));
-  e.beta = (const float*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)e.beta >> 32)) << 32) |
-                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint64_t)e.beta));
-  e.gamma = (const float*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)e.gamma >> 32)) << 32) |
-                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint64_t)e.gamma));
-  e.H = __builtin_amdgcn_readfirstlane(e.H);
-  e.W = __builtin_amdgcn_readfirstlane(e.W);
-  e.Cout = __builtin_amdgcn_readfirstlane(e.Cout);
-  e.act = __builtin_amdgcn_readfirstlane(e.act);
-  e.nphase = __builtin_amdgcn_readfirstlane(e.nphase);
-  e.s2d = __builtin_amdgcn_readfirstlane(e.s2d);
-  t.item = __builtin_amdgcn_readfirstlane(t.item);
-  t.tx = __builtin_amdgcn_readfirstlane(t.tx);
-  t.ty = __builtin_amdgcn_readfirstlane(t.ty);
-  t.n = __builtin_amdgcn_readfirstlane(t.n);
-  yreg_floats = __builtin_amdgcn_readfirstlane(yreg_floats);
-
-  const int pt = ht >> 3, pq = ht & 7;
-  const int ptx = pt & 7, pty = pt >> 3;
-  const float* yreg = lds + yreg_floats + pt * WP + 4 * pq;
-  floatx4 y[16];
-#pragma unroll
-  for (int p = 0; p < 16; ++p) y[p] = *(const floatx4*)(yreg + p * 32 * WP);
-  // per-channel parameters come from L1 every tile; channel groups beyond Cout read a clamped
-  // address and are never stored
-  unsigned cbyte[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int c0 = g * 32 + 4 * pq;
-    cbyte[g] = (unsigned)((c0 < e.Cout ? c0 : e.Cout - 4) * 4);
-  }
-  if (e.act == DSIC_ACT_GDN) {
-    wino_gdn_pairs<false>(y, e, cbyte);
-  } else if (e.act == DSIC_ACT_IGDN) {
-    wino_gdn_pairs<true>(y, e, cbyte);
-  } else {
-    const bool relu = e.act == DSIC_ACT_RELU;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const floatx4 pb = gload4(e.bias, cbyte[g]);
-#pragma unroll
-      for (int ij = 0; ij < 4; ++ij) {
-        floatx4 v = y[ij * 4 + g] + pb;
-        if (relu) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.f;
-        }
-        y[ij * 4 + g] = v;
-      }
-    }
-  }
-  // stores: uniform 64-bit image base + one 32-bit byte offset per output pixel (host checks the range)
-  const int phase = t.item & (e.nphase - 1);
-  const int ppy = phase >> 1, ppx = phase & 1;  // sub-pixel phase placement (ConvTranspose2d)
-  const int OH = e.nphase == 4 ? 2 * e.H : e.H, OW = e.nphase == 4 ? 2 * e.W : e.W;
-  __attribute__((address_space(1))) char* obase =
-      (__attribute__((address_space(1))) char*)(e.out + (size_t)t.n * OH * OW * e.Cout);
-#pragma unroll
-  for (int ij = 0; ij < 4; ++ij) {
-    const int oy = t.ty * 8 + 2 * pty + (ij >> 1);
-    const int ox = t.tx * 16 + 2 * ptx + (ij & 1);
-    if (oy < e.H && ox < e.W) {
-      const unsigned po =
-          (unsigned)(e.nphase == 4 ? ((2 * oy + ppy) * OW + (2 * ox + ppx)) * e.Cout
-                     : e.s2d       ? ((oy >> 1) * (e.W >> 1) + (ox >> 1)) * (4 * e.Cout) + ((oy & 1) * 2 + (ox & 1)) * e.Cout
-                                   : (oy * e.W + ox) * e.Cout) * 4u + 16u * pq;
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        if (g * 32 + 4 * pq < e.Cout)
-          *(__attribute__((address_space(1))) floatx4*)(obase + (size_t)po + g * 128) = y[ij * 4 + g];
-    }
-  }
-}
-
-
 // MODE 0: plain 3x3 layer.  MODE 1 (space-to-depth input) and MODE 2 (ConvTranspose2d phases) have
 // structurally zero Winograd positions whose MFMA clusters are skipped; MODE 0 carries no test in
 // the loop.  Steps run position-major (all four 8-channel groups of a position, then the next
@@ -272,9 +139,9 @@ static __device__ __noinline__ void wino_finish(WinoEpi e, WinoTile t, int yreg_
 // vmcnt retires in order, so a wave that mixes HBM-latency input loads with the L2-latency U
 // stream stalls its MFMAs behind the slowest input load; separate waves have separate counters.
 // 12 waves = 3 per SIMD: the kernel must fit 168 VGPRs (128 of them accumulators).
-// The helpers also run the whole output epilogue (bias, GDN/IGDN/ReLU, 16-byte stores): the MFMA
-// waves only fold their accumulators into the 2x2 outputs inside the free V buffer and go on to
-// the next tile, so VALU and store work overlaps the next tile's MFMAs.
+// The MFMA waves fold their accumulators into the 2x2 outputs inside the free V buffer (bias and
+// activation fused into the fold's second half) and go on to the next tile; the helpers copy the
+// finished outputs to HBM from there, behind the next chunk's input loads.
 // Every wave executes the same barrier sequence: P0, P, then per tile B_0..B_{n-1}, E1, E2.
 //
 // Tiles are handed out dynamically (first round = blockIdx.x, then a global ticket): a CU that is
@@ -373,12 +240,39 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
         *(floatx4*)(dst + (3 * 4 + nu) * 32 * WP) = sub4(r1, r3);
       }
     };
-    const WinoEpi epi = {a.out, a.bias, a.beta, a.gamma, a.H, a.W, a.Cout, a.act, a.nphase, a.s2d};
+    // Finished outputs of tile t (bias and activation already applied by the MFMA waves): LDS slots
+    // -> global memory, 16 bytes per lane.  The V plane layout of Y (plane p = 4*(2i+j) + g holds,
+    // for output pixel (i,j) of every Winograd tile, channels 32g..32g+31) means a helper thread
+    // reads exactly the 16 float4 slots it will overwrite with the next V.  Uniform 64-bit image
+    // base + one 32-bit byte offset per output pixel (the host checks the range).
+    auto next_ticket = [&]() { return (int)(atomicAdd(a.ticket, 1ULL) + gridDim.x); };
+    auto store_outputs = [&](const WinoTile& t, const float* yreg) {
+      const int phase = t.item & (a.nphase - 1);
+      const int ppy = phase >> 1, ppx = phase & 1;  // sub-pixel phase placement (ConvTranspose2d)
+      const int OH = a.nphase == 4 ? 2 * a.H : a.H, OW = a.nphase == 4 ? 2 * a.W : a.W;
+      char* obase = (char*)(a.out + (size_t)t.n * OH * OW * a.Cout);
+      const float* src = yreg + vwrite;
+#pragma unroll
+      for (int ij = 0; ij < 4; ++ij) {
+        const int oy = t.ty * 8 + 2 * pty + (ij >> 1);
+        const int ox = t.tx * 16 + 2 * ptx + (ij & 1);
+        if (oy < a.H && ox < a.W) {
+          const unsigned po =
+              (unsigned)(a.nphase == 4 ? ((2 * oy + ppy) * OW + (2 * ox + ppx)) * a.Cout
+                         : a.s2d       ? ((oy >> 1) * (a.W >> 1) + (ox >> 1)) * (4 * a.Cout) + ((oy & 1) * 2 + (ox & 1)) * a.Cout
+                                       : (oy * a.W + ox) * a.Cout) * 4u + 16u * pq;
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            if (g * 32 + 4 * pq < a.Cout)
+              *(floatx4*)(obase + (size_t)po + g * 128) = *(const floatx4*)(src + (ij * 4 + g) * 32 * WP);
+        }
+      }
+    };
     int tile_count = 0;
     (void)tile_count;
     if (ht == 0) {
       post(0, (int)blockIdx.x);  // grid <= ntiles
-      post(1, (int)(atomicAdd(a.ticket, 1ULL) + gridDim.x));
+      post(1, next_ticket());
     }
     wg_barrier();  // P0: the first two descriptors are posted
     WinoTile cur = read_slot(0);
@@ -417,19 +311,16 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
       };
       {  // chunk 0
         float* vnext = lds + (buf ^ 1) * WBUF;
-        if (have_y) {
-          if (!(WINO_ABL & 1)) wino_finish(epi, prev, (int)(vnext - lds), ht);
-        }
-        // the ticket for the tile after next: behind the epilogue call (a callee waits for every
-        // outstanding memory operation on entry) and ahead of the input loads, so that it is the
-        // oldest entry of this wave's in-order vmcnt queue and its latency hides behind theirs
+        // the ticket for the tile after next first (its return is then the oldest entry of this
+        // wave's in-order vmcnt queue), then the input loads of target 0, and only then the stores
+        // of the previous tile's outputs: the loads' latency passes during the copy, and no load
+        // waits behind a store
         int ticket = 0;
-        if (ht == 0 && more) ticket = (int)(atomicAdd(a.ticket, 1ULL) + gridDim.x);
-        // (always aimed and loaded, so that the patch registers are defined on every path after the
-        //  call above; without a target the loads re-read this tile and are dropped)
+        if (ht == 0 && more) ticket = next_ticket();
         const bool tgt0 = nchunks > 1 || more;
         aim(m, nchunks == 1 && more ? nxt : cur);
         issue(d, m, nchunks == 1 ? 0 : 1);
+        if (have_y && !(WINO_ABL & 1)) store_outputs(prev, vnext);
         if (tgt0) commit(d, m, vnext);
         if (ht == 0 && more) post(s_wr, ticket);
         pre_aim(0);
@@ -454,7 +345,7 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
       s_nxt = s_wr;
       s_wr = s_old == 0 ? 2 : s_old - 1;  // ring 0,1,2: cur slot of the finished tile becomes writable
     }
-    if (have_y) wino_finish(epi, prev, (buf ^ 1) * WBUF, ht);  // outputs of the last tile
+    if (have_y) store_outputs(prev, lds + (buf ^ 1) * WBUF);  // outputs of the last tile
 #if WINO_STAMP
     if (wave == 8 && lane < 32) wino_stamps[blockIdx.x * 32 + lane] = ((long long*)(lds + 2 * WBUF + 16))[lane];
 #endif
@@ -490,6 +381,18 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
   const unsigned soff0 = (unsigned)(ph * 8 + (PDIR > 0 ? 0 : 7)) * step_p;  // first fragment of a tile
   const int aread = ((ph * 8) * 32 + l31) * WP + 4 * h;  // + p*32*WP + sub*8
   auto pos_of = [](int it) { return PDIR > 0 ? it >> 2 : 7 - (it >> 2); };
+  // epilogue parameters of this lane's output channel
+  float pbias = 0.f, pbeta = 1.f, pgamma = 0.f;
+  {
+    const int col = nt * 32 + l31;
+    if (col < a.Cout) {
+      pbias = a.bias[col];
+      if (a.act == DSIC_ACT_GDN || a.act == DSIC_ACT_IGDN) {
+        pbeta = a.beta[col];
+        pgamma = a.gamma[col];
+      }
+    }
+  }
   const int stamp_wave = 0;
   int tile_count = 0;
   (void)stamp_wave; (void)tile_count;
@@ -615,17 +518,43 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
       }
       wg_barrier();  // E1
       STAMP(25);
+      // The wave that adds the second term holds the finished sum in registers, so bias and
+      // activation are applied right here (this lane = one output channel: its three parameters
+      // live in registers) and the helpers only copy the result out.
+      auto finish_rows = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        floatx16 got;
+        for (int j = 0; j < 2; ++j) {
+          floatx16 got;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) got[e] = yoth[(4 * j * 32 + (e & 3) + 8 * (e >> 2)) * WP];
+          for (int e = 0; e < 16; ++e) got[e] = yoth[(4 * j * 32 + (e & 3) + 8 * (e >> 2)) * WP];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) yoth[(4 * j * 32 + (e & 3) + 8 * (e >> 2)) * WP] = got[e] + send[j][e];
-      }
+          for (int e = 0; e < 16; e += 2) {
+            floatx2 v = {got[e], got[e + 1]};
+            v = v + floatx2{send[j][e], send[j][e + 1]};
+            v = v + floatx2{pbias, pbias};
+            if (ACT == DSIC_ACT_GDN || ACT == DSIC_ACT_IGDN) {
+              v = gdn_pair<ACT == DSIC_ACT_IGDN>(v, floatx2{pbeta, pbeta}, floatx2{pgamma, pgamma});
+            } else if (ACT == DSIC_ACT_RELU) {
+              v[0] = v[0] > 0.f ? v[0] : 0.f;
+              v[1] = v[1] > 0.f ? v[1] : 0.f;
+            }
+            yoth[(4 * j * 32 + (e & 3) + 8 * (e >> 2)) * WP] = v[0];
+            yoth[(4 * j * 32 + ((e + 1) & 3) + 8 * ((e + 1) >> 2)) * WP] = v[1];
+          }
+        }
+      };
+      if (a.act == DSIC_ACT_GDN)
+        finish_rows(std::integral_constant<int, DSIC_ACT_GDN>{});
+      else if (a.act == DSIC_ACT_IGDN)
+        finish_rows(std::integral_constant<int, DSIC_ACT_IGDN>{});
+      else if (a.act == DSIC_ACT_RELU)
+        finish_rows(std::integral_constant<int, DSIC_ACT_RELU>{});
+      else
+        finish_rows(std::integral_constant<int, DSIC_ACT_NONE>{});
     }
     STAMP(26);
-    wg_barrier();  // E2: the helpers take Y from here (activation + stores) and refill the buffer
+    wg_barrier();  // E2: the helpers copy the finished outputs from here and refill the buffer
     STAMP(27);
     cur = nxt;
     s_nxt = s_nxt == 2 ? 0 : s_nxt + 1;
