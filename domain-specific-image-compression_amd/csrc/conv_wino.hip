@@ -97,8 +97,13 @@ struct WinoArgs {
 __device__ long long wino_stamps[256 * 32];
 // cycle stamps go to LDS (a global store would sit in the wave's in-order vmcnt queue and perturb
 // what is measured) and are copied out when the workgroup ends
-#define STAMP_AT(w, i) \
-  if (WINO_STAMP && lane == 0 && wave == (w) && tile_count == WINO_STAMP_TILE) ((long long*)(lds + 2 * WBUF + 16))[i] = __builtin_amdgcn_s_memtime()
+#define STAMP_AT(w, i)                                                                            \
+  do {                                                                                            \
+    __builtin_amdgcn_sched_barrier(0); /* s_memtime does not depend on the MFMAs around it */   \
+    if (WINO_STAMP && lane == 0 && wave == (w) && tile_count == WINO_STAMP_TILE)                  \
+      ((long long*)(lds + 2 * WBUF + 16))[i] = __builtin_amdgcn_s_memtime();                      \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+  } while (0)
 #define STAMP(i) STAMP_AT(0, i)
 #else
 #define STAMP(i)
