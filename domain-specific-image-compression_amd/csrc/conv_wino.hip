@@ -281,28 +281,30 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
     }
     wg_barrier();  // P0: the first two descriptors are posted
     WinoTile cur = read_slot(0);
-    {
-      Aim m;
-      floatx4 d[16];
-      aim(m, cur);
-      issue(d, m, 0);
-      commit(d, m, lds);
+    // The patch in flight and its aim live across tiles: the aim moves on to the next tile two
+    // chunks before the current one ends, and (layers with more than one chunk) the loads of the next
+    // tile's target 0 are issued before the fold barriers of the current one, so their latency and
+    // that of the ticket fetch pass while the MFMA waves fold.
+    Aim m;
+    floatx4 d[16];
+    int ticket_pre = a.ntiles;  // ticket for the descriptor posted in the coming tile's chunk 0 (thread 0)
+    aim(m, cur);
+    issue(d, m, 0);
+    commit(d, m, lds);
+    if (nchunks > 1) {
+      if (ht == 0 && read_slot(1).item < a.ntiles) ticket_pre = next_ticket();
+      issue(d, m, 1);  // target 0 of the first tile
     }
     wg_barrier();  // P
     int buf = 0, s_nxt = 1, s_wr = 2;
     WinoTile prev = cur;
-    bool have_y = false;  // Y of tile `prev` waits in V[buf^1]
+    bool have_y = false;  // finished outputs of tile `prev` wait in V[buf^1]
     while (cur.item < a.ntiles) {
       const WinoTile nxt = read_slot(s_nxt);
       const bool more = nxt.item < a.ntiles;
       tile_count++;
-      floatx4 d[16];  // the patch in flight; dead across tiles
-      Aim m;          // likewise: re-aimed after the epilogue call, so nothing big lives across it
       // chunk c: the MFMA waves consume V[buf]; the helpers fill V[buf^1] with target c =
-      // (cur, c+1), or (nxt, 0) for the last chunk.  Target 0 is loaded in chunk 0 itself (after the
-      // outputs of the previous tile have left, see finish_store); targets 1.. are put in flight
-      // one chunk early, before the barrier.
-      // Target chunk+1 = (cur, chunk+2) or (nxt, 0): re-aiming is VALU work and happens before the
+      // (cur, c+1), or (nxt, 0) for the last chunk.  Re-aiming is VALU work and happens before the
       // barrier; the 16 buffer loads need no VALU and are issued right behind the barrier, where
       // they fly during the MFMA phase.
       auto pre_aim = [&](int chunk) {
@@ -316,15 +318,16 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
       };
       {  // chunk 0
         float* vnext = lds + (buf ^ 1) * WBUF;
-        // the ticket for the tile after next first (its return is then the oldest entry of this
-        // wave's in-order vmcnt queue), then the input loads of target 0, and only then the stores
-        // of the previous tile's outputs: the loads' latency passes during the copy, and no load
-        // waits behind a store
-        int ticket = 0;
-        if (ht == 0 && more) ticket = next_ticket();
         const bool tgt0 = nchunks > 1 || more;
-        aim(m, nchunks == 1 && more ? nxt : cur);
-        issue(d, m, nchunks == 1 ? 0 : 1);
+        int ticket = ticket_pre;
+        if (nchunks == 1) {
+          // single-chunk layer: target 0 is (nxt, 0).  Ticket first (its return is then the oldest
+          // entry of this wave's in-order vmcnt queue), then the input loads, then the output copy:
+          // the loads' latency passes during the copy and no load waits behind a store.
+          if (ht == 0 && more) ticket = next_ticket();
+          aim(m, more ? nxt : cur);
+          issue(d, m, 0);
+        }
         if (have_y && !(WINO_ABL & 1)) store_outputs(prev, vnext);
         if (tgt0) commit(d, m, vnext);
         if (ht == 0 && more) post(s_wr, ticket);
@@ -341,8 +344,14 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
         post_issue(chunk);
         buf ^= 1;
       }
+      if (nchunks > 1 && more) {
+        // next tile's target 0 = (nxt, 1) (the aim is on nxt since chunk nchunks-2) and the ticket
+        // for the descriptor it will post: both in flight across the fold barriers
+        if (ht == 0 && read_slot(s_wr).item < a.ntiles) ticket_pre = next_ticket();
+        issue(d, m, 1);
+      }
       wg_barrier();  // E1
-      wg_barrier();  // E2: Y of this tile is complete in V[buf^1]
+      wg_barrier();  // E2: the finished outputs of this tile lie in V[buf^1]
       prev = cur;
       have_y = true;
       cur = nxt;
