@@ -46,6 +46,7 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef int intx4 __attribute__((ext_vector_type(4)));
 typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 
 // a - b on two / four / sixteen floats with packed fp32 instructions.  The compiler packs fp32
 // additions (v_pk_add_f32) but leaves subtractions scalar; the negation is an operand modifier of
@@ -245,31 +246,47 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
         *(floatx4*)(dst + (3 * 4 + nu) * 32 * WP) = sub4(r1, r3);
       }
     };
-    // Finished outputs of tile t (bias and activation already applied by the MFMA waves): LDS slots
+    // Finished outputs of a tile (bias and activation already applied by the MFMA waves): LDS slots
     // -> global memory, 16 bytes per lane.  The V plane layout of Y (plane p = 4*(2i+j) + g holds,
     // for output pixel (i,j) of every Winograd tile, channels 32g..32g+31) means a helper thread
-    // reads exactly the 16 float4 slots it will overwrite with the next V.  Uniform 64-bit image
-    // base + one 32-bit byte offset per output pixel (the host checks the range).
+    // reads exactly the 16 float4 slots it will overwrite with the next V.
+    // Two steps: aim_out(tile) computes, while the MFMA waves fold, a buffer descriptor of the output
+    // image and one byte offset per output pixel (out of range for a pixel beyond the image: the
+    // hardware drops that store); store_outputs() is then nothing but 16 LDS reads and 16 buffer
+    // stores - no VALU work, so the copy runs beside the next tile's MFMAs.
+    struct OutAim {
+      unsigned po[4];
+      __amdgpu_buffer_rsrc_t rs;
+    };
     auto next_ticket = [&]() { return (int)(atomicAdd(a.ticket, 1ULL) + gridDim.x); };
-    auto store_outputs = [&](const WinoTile& t, const float* yreg) {
+    auto aim_out = [&](OutAim& o, const WinoTile& t) {
       const int phase = t.item & (a.nphase - 1);
       const int ppy = phase >> 1, ppx = phase & 1;  // sub-pixel phase placement (ConvTranspose2d)
       const int OH = a.nphase == 4 ? 2 * a.H : a.H, OW = a.nphase == 4 ? 2 * a.W : a.W;
-      char* obase = (char*)(a.out + (size_t)t.n * OH * OW * a.Cout);
-      const float* src = yreg + vwrite;
+      o.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)t.n * OH * OW * a.Cout), 0,
+                                               OH * OW * a.Cout * 4, 0x00020000);  // host checks < 2 GiB
 #pragma unroll
       for (int ij = 0; ij < 4; ++ij) {
         const int oy = t.ty * 8 + 2 * pty + (ij >> 1);
         const int ox = t.tx * 16 + 2 * ptx + (ij & 1);
-        if (oy < a.H && ox < a.W) {
-          const unsigned po =
-              (unsigned)(a.nphase == 4 ? ((2 * oy + ppy) * OW + (2 * ox + ppx)) * a.Cout
-                         : a.s2d       ? ((oy >> 1) * (a.W >> 1) + (ox >> 1)) * (4 * a.Cout) + ((oy & 1) * 2 + (ox & 1)) * a.Cout
-                                       : (oy * a.W + ox) * a.Cout) * 4u + 16u * pq;
+        const unsigned po =
+            (unsigned)(a.nphase == 4 ? ((2 * oy + ppy) * OW + (2 * ox + ppx)) * a.Cout
+                       : a.s2d       ? ((oy >> 1) * (a.W >> 1) + (ox >> 1)) * (4 * a.Cout) + ((oy & 1) * 2 + (ox & 1)) * a.Cout
+                                     : (oy * a.W + ox) * a.Cout) * 4u + 16u * pq;
+        o.po[ij] = oy < a.H && ox < a.W ? po : 0x80000000u;
+      }
+    };
+    auto store_outputs = [&](const OutAim& o, const float* yreg) {
+      const float* src = yreg + vwrite;
+      const int ngroups = (a.Cout + 31) >> 5;
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
-            if (g * 32 + 4 * pq < a.Cout)
-              *(floatx4*)(obase + (size_t)po + g * 128) = *(const floatx4*)(src + (ij * 4 + g) * 32 * WP);
+      for (int g = 0; g < 4; ++g) {
+        if (g >= ngroups) break;                                      // uniform
+        if (g == ngroups - 1 && g * 32 + 4 * pq >= a.Cout) continue;  // partial last group (Cout % 32 != 0)
+#pragma unroll
+        for (int ij = 0; ij < 4; ++ij) {
+          const floatx4 v = *(const floatx4*)(src + (ij * 4 + g) * 32 * WP);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), o.rs, o.po[ij], g * 128, 0);
         }
       }
     };
@@ -297,8 +314,11 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
     }
     wg_barrier();  // P
     int buf = 0, s_nxt = 1, s_wr = 2;
-    WinoTile prev = cur;
-    bool have_y = false;  // finished outputs of tile `prev` wait in V[buf^1]
+    OutAim oa;
+    oa.rs = m.rsrc;  // (defined on every path; aimed before the first fold)
+#pragma unroll
+    for (int ij = 0; ij < 4; ++ij) oa.po[ij] = 0x80000000u;
+    bool have_y = false;  // finished outputs of the previous tile wait in V[buf^1], aimed by oa
     while (cur.item < a.ntiles) {
       const WinoTile nxt = read_slot(s_nxt);
       const bool more = nxt.item < a.ntiles;
@@ -328,7 +348,7 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
           aim(m, more ? nxt : cur);
           issue(d, m, 0);
         }
-        if (have_y && !(WINO_ABL & 1)) store_outputs(prev, vnext);
+        if (have_y && !(WINO_ABL & 1)) store_outputs(oa, vnext);
         if (tgt0) commit(d, m, vnext);
         if (ht == 0 && more) post(s_wr, ticket);
         pre_aim(0);
@@ -350,16 +370,16 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
         if (ht == 0 && read_slot(s_wr).item < a.ntiles) ticket_pre = next_ticket();
         issue(d, m, 1);
       }
+      aim_out(oa, cur);  // VALU work, done while the MFMA waves fold
       wg_barrier();  // E1
       wg_barrier();  // E2: the finished outputs of this tile lie in V[buf^1]
-      prev = cur;
       have_y = true;
       cur = nxt;
       const int s_old = s_nxt;
       s_nxt = s_wr;
       s_wr = s_old == 0 ? 2 : s_old - 1;  // ring 0,1,2: cur slot of the finished tile becomes writable
     }
-    if (have_y) store_outputs(prev, lds + (buf ^ 1) * WBUF);  // outputs of the last tile
+    if (have_y) store_outputs(oa, lds + (buf ^ 1) * WBUF);  // outputs of the last tile
 #if WINO_STAMP
     if (wave == 8 && lane < 32) wino_stamps[blockIdx.x * 32 + lane] = ((long long*)(lds + 2 * WBUF + 16))[lane];
 #endif

@@ -27,3 +27,5 @@ for c in range(4):
     if c < 3: print(f"          gap to next chunk {d(4*c+3, 4*c+4):8.0f}")
 print(f"fold + own stores -> E1 {d(24, 25):8.0f}   partner row added {d(25, 26):8.0f}   E2 {d(26, 27):8.0f}")
 print(f"MFMA-wave tile total (chunk0 start -> after E2) {d(0, 27):8.0f}")
+order = list(range(16)) + [24, 25, 26, 27]
+print("raw deltas:", " ".join(f"{a}->{b}:{d(a, b):.0f}" for a, b in zip(order[:-1], order[1:])))
