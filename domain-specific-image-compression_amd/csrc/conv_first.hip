@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_kernel(
         const size_t o = s2d ? (((size_t)n * (H >> 1) + (oy >> 1)) * (W >> 1) + (ox >> 1)) * (4 * Cout) +
                                    ((oy & 1) * 2 + (ox & 1)) * Cout + nn
                              : (((size_t)n * H + oy) * W + ox) * Cout + nn;
-        *(floatx4*)(out + o) = v;
+        __builtin_nontemporal_store(v, (floatx4*)(out + o));
       }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);

@@ -119,6 +119,9 @@ constexpr int WTHREADS = 768;              // 8 MFMA waves + 4 helper waves
 #ifndef WINO_RING
 #define WINO_RING 4                        // U fragments in flight per MFMA wave (2 or 4)
 #endif
+#ifndef WINO_NT_OUT
+#define WINO_NT_OUT 0  // cache policy of the output stores (2 = nt is 1 % faster per layer but 1-3 % slower per step: the next layer finds small outputs in L2/MALL)
+#endif
 #ifndef WINO_CPRIO
 #define WINO_CPRIO 1                       // wave priority of an MFMA wave inside an MFMA cluster
 #endif
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
 #pragma unroll
         for (int ij = 0; ij < 4; ++ij) {
           const floatx4 v = *(const floatx4*)(src + (ij * 4 + g) * 32 * WP);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), o.rs, o.po[ij], g * 128, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), o.rs, o.po[ij], g * 128, WINO_NT_OUT);
         }
       }
     };
