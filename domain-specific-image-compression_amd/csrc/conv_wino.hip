@@ -92,6 +92,7 @@ struct WinoArgs {
   int s2d_in;  // input is the space-to-depth image of a 5x5/s2 layer: Cin = 4*Cs, channel block (a,b)
   int s2d;  // store space-to-depth: [B,H/2,W/2,4*Cout] (feeds a 5x5/s2 layer run as 3x3 over 4*C)
   int tiles_x, tiles_y, ntiles;  // 16x8-pixel output tiles
+  int nt_out;  // stream the output past the caches (set by the host for outputs beyond the MALL's size)
 };
 
 #if WINO_STAMP
@@ -119,8 +120,8 @@ constexpr int WTHREADS = 768;              // 8 MFMA waves + 4 helper waves
 #ifndef WINO_RING
 #define WINO_RING 4                        // U fragments in flight per MFMA wave (2 or 4)
 #endif
-#ifndef WINO_NT_OUT
-#define WINO_NT_OUT 0  // cache policy of the output stores (2 = nt is 1 % faster per layer but 1-3 % slower per step: the next layer finds small outputs in L2/MALL)
+#ifndef WINO_NT_BYTES
+#define WINO_NT_BYTES (300ll << 20)  // outputs larger than this are stored non-temporal (they cannot stay in the 256 MB MALL)
 #endif
 #ifndef WINO_CPRIO
 #define WINO_CPRIO 1                       // wave priority of an MFMA wave inside an MFMA cluster
@@ -289,7 +290,10 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
 #pragma unroll
         for (int ij = 0; ij < 4; ++ij) {
           const floatx4 v = *(const floatx4*)(src + (ij * 4 + g) * 32 * WP);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), o.rs, o.po[ij], g * 128, WINO_NT_OUT);
+          if (a.nt_out)  // uniform
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), o.rs, o.po[ij], g * 128, 2);
+          else
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), o.rs, o.po[ij], g * 128, 0);
         }
       }
     };
@@ -756,6 +760,9 @@ static int wino_launch(WinoArgs& a, hipStream_t st) {
   DSIC_REQUIRE((int64_t)16 * (a.Cin / 8) * a.CoutP * 8 * 4 * a.nphase < ((int64_t)1 << 31),
                "conv3x3_wino: transformed weights must stay below 2 GiB");
   a.ntiles = (int)nt;
+  // Small outputs are read back by the next layer from L2/MALL (cached stores measured 1-3 % faster per
+  // step); an output that cannot stay there anyway is streamed (1 % faster per layer).
+  a.nt_out = (int64_t)B * H * W * a.Cout * 4 * (a.nphase == 4 ? 4 : 1) > WINO_NT_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv_wino_kernel<0>,
