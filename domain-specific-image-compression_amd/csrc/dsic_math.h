@@ -1,5 +1,6 @@
-// Deterministic float64 special functions for the CDF tables of the entropy
-// path (eval_selfcontained_entropy.py:14-15 gaussian_cdf, :57-58 StudentT.cdf).
+// Deterministic special functions + the float32 table flow for the CDF tables of the
+// entropy path (eval_selfcontained_entropy.py:14-15 gaussian_cdf, :17-23
+// pmf_to_uint16_cdf, :41-47 z PMF, :57-58 StudentT.cdf).
 //
 // Bit-exactness between this GPU code and a CPU implementation cannot rest on
 // libm / ocml (their exp, log, lgamma, erf differ in the last ulps, which the
@@ -202,27 +203,109 @@ DM_HD double student_t_cdf(double t, double nu) {
   return t > 0 ? 1.0 - tail : tail;
 }
 
-// Boundary CDF values F[0..L] -> coder table c[0..L-1] (uint16; c[L] = 65536 is
-// implicit).  pmf clamp 1e-12 + renormalise (:45-46), pmf_to_uint16_cdf (:17-23),
-// then the spreading c[k] = floor(u16[k] (65536-L) / 65535) + k that keeps every
-// symbol's interval non-empty.  `work` holds L doubles.
-DM_HD void finish_table(const double* F, int L, uint16_t* out, double* work) {
-  double total = 0.0;
-  for (int k = 0; k < L; ++k) {
-    double p = F[k + 1] - F[k];
-    if (p < 1e-12) p = 1e-12;
-    work[k] = p;
-    total = total + p;
+// ---- float32 table flow (eval_selfcontained_entropy.py:14-23, :41-47) ----------------------
+// The reference evaluates the tables with float32 CPU-torch tensors; the steps below follow
+// its operation order one by one (pinned by tests/golden/entropy_ref.npz, generated from the
+// reference's own lines).  All float32 operations here are single IEEE operations
+// (-ffp-contract=off, correctly rounded division), so host and device agree bit for bit.
+
+// erf(u), u >= 0, float64: series below 1.5, 1 - Laplace continued fraction above.
+DM_HD double erf_pos(double u) {
+  if (u < 1.5) {
+    const double u2 = u * u;
+    double term = u, sum = u;
+    for (int n = 1; n < 200; ++n) {
+      term = term * (2.0 * u2) / (double)(2 * n + 1);
+      sum = sum + term;
+      if (term < sum * 1e-17) break;
+    }
+    return 2.0 * DM_INV_SQRT_PI * exp(-u2) * sum;
   }
+  if (u > 6.0) return 1.0;
+  return 1.0 - erfc_pos(u);
+}
+
+// float32 erf = the float64 value rounded once (<= 0.5 ulp).  torch's CPU erf (Intel MKL VML
+// vsErf, closed source, < 1 ulp) differs from it in the last bit for ~1.5 % of arguments; that
+// is the only step of the z-table flow that is not the reference's bits.
+DM_HD float erff_rn(float a) {
+  const double u = (double)a;
+  if (u != u) return a;
+  return u < 0 ? -(float)erf_pos(-u) : (float)erf_pos(u);
+}
+
+// :15 in float32: 0.5 * (1 + erf(x / float(sqrt 2)))
+DM_HD float gaussian_cdf_f32(float x) {
+  const float a = x / 1.41421354f;
+  const float e = erff_rn(a);
+  const float s = 1.0f + e;
+  return 0.5f * s;
+}
+
+// torch.sum(dim=0) of float32 on the CPU, per output element (aten cascade sum): runs of 16
+// added sequentially, run sums collected on level 1, level 1 flushed to level 2 at index
+// multiples of 256, level 2 to level 3 at multiples of 4096; remainder, then levels low to high.
+DM_HD float sum_f32_torch(const float* p, int n) {
+  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+  int i = 0;
+  while (i + 16 <= n) {
+    for (int j = 0; j < 16; ++j, ++i) a0 = a0 + p[i];
+    a1 = a1 + a0;
+    a0 = 0.0f;
+    if ((i & 0xF0) == 0) {
+      a2 = a2 + a1;
+      a1 = 0.0f;
+      if ((i & 0xF00) == 0) {
+        a3 = a3 + a2;
+        a2 = 0.0f;
+      }
+    }
+  }
+  for (; i < n; ++i) a0 = a0 + p[i];
+  a0 = a0 + a1;
+  a0 = a0 + a2;
+  a0 = a0 + a3;
+  return a0;
+}
+
+// Boundary CDF values F[0..L] (float32) -> coder table c[0..L-1] (uint16; c[L] = 65536 is
+// implicit).  pmf clamp 1e-12 (:45), float32 sum + divide (:46), pmf_to_uint16_cdf (:17-23:
+// cumsum with a float64 accumulator whose prefixes are rounded to float32, last >= 1,
+// * 65535.0f, clamp, truncate), then the spreading c[k] = floor(u16[k] (65536-L) / 65535) + k
+// that keeps every symbol's interval non-empty.  `pmf` holds L floats; raw (optional, may be
+// null) receives the pre-spreading u16[0..L].
+DM_HD void finish_table(const float* F, int L, uint16_t* out, float* pmf, uint16_t* raw) {
+  for (int k = 0; k < L; ++k) {
+    float p = F[k + 1] - F[k];
+    if (p < 1e-12f) p = 1e-12f;
+    pmf[k] = p;
+  }
+  const float total = sum_f32_torch(pmf, L);
   double cum = 0.0;
+  uint32_t u16 = 0;
   for (int k = 0; k < L; ++k) {
-    double sc = cum * 65535.0;
-    if (sc < 0.0) sc = 0.0;
-    if (sc > 65535.0) sc = 65535.0;
-    const uint32_t u16 = (uint32_t)sc;
     out[k] = (uint16_t)((uint32_t)(((uint64_t)u16 * (uint64_t)(65536 - L)) / 65535u) + (uint32_t)k);
-    cum = cum + work[k] / total;
+    if (raw) raw[k] = (uint16_t)u16;
+    const float q = pmf[k] / total;
+    cum = cum + (double)q;
+    float c = (float)cum;
+    if (k == L - 1 && c < 1.0f) c = 1.0f;
+    float sc = c * 65535.0f;
+    if (sc < 0.0f) sc = 0.0f;
+    if (sc > 65535.0f) sc = 65535.0f;
+    u16 = (uint32_t)sc;
   }
+  if (raw) raw[L] = (uint16_t)u16;
+}
+
+// Boundary k of a support starting at smin: float(smin + k) - 0.5f (= lower[k] = upper[k-1], :43).
+DM_HD float boundary_f32(int smin, int k) { return (float)(smin + k) - 0.5f; }
+DM_HD float table_cdf_gauss(int smin, int k, float sigma) {
+  return gaussian_cdf_f32(boundary_f32(smin, k) / sigma);
+}
+// :57-58 (not executable in the reference): float64 t CDF of b/sigma, rounded once to float32.
+DM_HD float table_cdf_student(int smin, int k, float sigma, float nu) {
+  return (float)student_t_cdf((double)boundary_f32(smin, k) / (double)sigma, (double)nu);
 }
 
 }  // namespace dm

@@ -7,8 +7,8 @@
 // resolution).  Interpretation choices are frozen in DESIGN.md "Entropy path".
 //
 // Parallel structure: tables are embarrassingly parallel (one wave per
-// (image, channel) table: 64 lanes evaluate the boundary CDFs in float64, lane 0
-// does the short sequential normalise/cumsum/quantise).  The coder's interval
+// (image, channel) table: 64 lanes evaluate the boundary CDFs, lane 0 does the
+// short sequential normalise/cumsum/quantise in the reference's float32 order).  The coder's interval
 // update is a serial dependency chain per stream, so there is one workgroup
 // (one wave) per (image, stream): all 64 lanes translate a chunk of symbols to
 // (c_low, c_high) pairs in LDS, then lane 0 walks the chunk.  Matching leading
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void tables_kernel(const float* __restrict__ s
                                                      const int* __restrict__ meta, int meta_off,
                                                      uint16_t* __restrict__ tables, int C, int Lmax,
                                                      int ntables, int* __restrict__ err) {
-  extern __shared__ double shm[];  // per wave: F[Lmax+1], work[Lmax]
+  extern __shared__ float shm[];  // per wave: F[Lmax+1], pmf[Lmax]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int tid = blockIdx.x * 4 + wave;
   if (tid >= ntables) return;
@@ -75,17 +75,15 @@ __global__ __launch_bounds__(256) void tables_kernel(const float* __restrict__ s
     if (lane == 0) atomicOr(err, 1);
     return;
   }
-  double* F = shm + (size_t)wave * (2 * Lmax + 1);
-  double* work = F + Lmax + 1;
-  const double sg = (double)sigma[(size_t)b * sb + c];
-  const double nv = STUDENT ? (double)nu[(size_t)b * sb + c] : 0.0;
-  for (int k = lane; k <= L; k += 64) {
-    const double x = ((double)(smin + k) - 0.5) / sg;
-    F[k] = STUDENT ? dm::student_t_cdf(x, nv) : dm::normal_cdf(x);
-  }
+  float* F = shm + (size_t)wave * (2 * Lmax + 1);
+  float* pmf = F + Lmax + 1;
+  const float sg = sigma[(size_t)b * sb + c];
+  const float nv = STUDENT ? nu[(size_t)b * sb + c] : 0.0f;
+  for (int k = lane; k <= L; k += 64)
+    F[k] = STUDENT ? dm::table_cdf_student(smin, k, sg, nv) : dm::table_cdf_gauss(smin, k, sg);
   __builtin_amdgcn_s_waitcnt(0xc07f);
   __builtin_amdgcn_wave_barrier();
-  if (lane == 0) dm::finish_table(F, L, tables + ((size_t)b * C + c) * Lmax, work);
+  if (lane == 0) dm::finish_table(F, L, tables + ((size_t)b * C + c) * Lmax, pmf, nullptr);
 }
 
 // Range encoder, one wave per (image, stream): stream id = b*2 + which (0: z string,
@@ -430,7 +428,7 @@ static int tables_launch(bool student, const float* sigma, const float* nu, int 
   DSIC_REQUIRE(sigma && meta && tables && err && (!student || nu), "cdf_tables: null pointer");
   DSIC_REQUIRE(B > 0 && C > 0 && Lmax >= 1 && Lmax <= 1000, "cdf_tables: Lmax=%d must be in [1,1000]", Lmax);
   const int ntables = B * C;
-  const size_t shm = (size_t)4 * (2 * Lmax + 1) * sizeof(double);
+  const size_t shm = (size_t)4 * (2 * Lmax + 1) * sizeof(float);
   const int sb = per_image ? C : 0;
   if (student)
     hipLaunchKernelGGL(tables_kernel<true>, dim3(ceil_div(ntables, 4)), dim3(256), shm, st, sigma, nu, sb,
@@ -510,14 +508,32 @@ extern "C" int dsic_stream_destroy(void* stream) {
 // oracle without a GPU; the device kernels are compared on the GPU box).
 extern "C" double dsic_host_normal_cdf(double x) { return dm::normal_cdf(x); }
 extern "C" double dsic_host_student_t_cdf(double t, double nu) { return dm::student_t_cdf(t, nu); }
-extern "C" int dsic_host_cdf_table(int student, float sigma, float nu, int smin, int L,
-                                   uint16_t* out_host) {
-  DSIC_REQUIRE(out_host && L >= 1 && L <= 4096, "host_cdf_table: bad argument");
-  double F[4097], work[4096];
-  for (int k = 0; k <= L; ++k) {
-    const double x = ((double)(smin + k) - 0.5) / (double)sigma;
-    F[k] = student ? dm::student_t_cdf(x, (double)nu) : dm::normal_cdf(x);
+extern "C" float dsic_host_gaussian_cdf_f32(float x) { return dm::gaussian_cdf_f32(x); }
+extern "C" float dsic_host_exp_f32(float x) { return (float)dm::exp((double)x); }
+extern "C" int dsic_host_pmf_to_uint16_cdf(const float* pmf_host, int L, int C, uint16_t* out_host) {
+  // :17-23 on a host pmf [L][C] (support axis first, like the reference) -> out [L+1][C]
+  DSIC_REQUIRE(pmf_host && out_host && L >= 1 && C >= 1, "host_pmf_to_uint16_cdf: bad argument");
+  for (int c = 0; c < C; ++c) {
+    double cum = 0.0;
+    out_host[c] = 0;
+    for (int k = 0; k < L; ++k) {
+      cum = cum + (double)pmf_host[(size_t)k * C + c];
+      float v = (float)cum;
+      if (k == L - 1 && v < 1.0f) v = 1.0f;
+      float sc = v * 65535.0f;
+      if (sc < 0.0f) sc = 0.0f;
+      if (sc > 65535.0f) sc = 65535.0f;
+      out_host[(size_t)(k + 1) * C + c] = (uint16_t)sc;
+    }
   }
-  dm::finish_table(F, L, out_host, work);
+  return DSIC_OK;
+}
+extern "C" int dsic_host_cdf_table(int student, float sigma, float nu, int smin, int L,
+                                   uint16_t* out_host, uint16_t* raw_host) {
+  DSIC_REQUIRE(out_host && L >= 1 && L <= 4096, "host_cdf_table: bad argument");
+  float F[4097], pmf[4096];
+  for (int k = 0; k <= L; ++k)
+    F[k] = student ? dm::table_cdf_student(smin, k, sigma, nu) : dm::table_cdf_gauss(smin, k, sigma);
+  dm::finish_table(F, L, out_host, pmf, raw_host);
   return DSIC_OK;
 }

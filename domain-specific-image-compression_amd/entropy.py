@@ -34,10 +34,34 @@ def _check_err(err, what):
 
 
 def gaussian_cdf(x):
-    """:14-15, float64 on the host through the library's own table math."""
+    """:14-15 in float32, like the reference's CPU torch evaluation (host, through the
+    library's own table math: x / float(sqrt 2), erf, 1 + ., 0.5 * .)."""
     L = _lib.load()
-    a = np.asarray(x, dtype=np.float64)
-    return np.array([L.dsic_host_normal_cdf(float(v)) for v in a.ravel()]).reshape(a.shape)
+    a = np.asarray(x, dtype=np.float32)
+    return np.array([L.dsic_host_gaussian_cdf_f32(float(v)) for v in a.ravel()], dtype=np.float32).reshape(a.shape)
+
+
+def pmf_to_uint16_cdf(pmf):
+    """:17-23 on the host: pmf [L, C, ...] float32 (support axis first) -> uint16 [L+1, C, ...]."""
+    L = _lib.load()
+    p = np.ascontiguousarray(np.asarray(pmf, dtype=np.float32))
+    Ls = p.shape[0]
+    C = int(np.prod(p.shape[1:], dtype=np.int64)) if p.ndim > 1 else 1
+    out = np.empty((Ls + 1, C), dtype=np.uint16)
+    _lib.check(L.dsic_host_pmf_to_uint16_cdf(p.ctypes.data_as(ctypes.c_void_p), Ls, C,
+                                             out.ctypes.data_as(ctypes.c_void_p)), "pmf_to_uint16_cdf")
+    return out.reshape((Ls + 1,) + p.shape[1:])
+
+
+def sigma_z_of(model):
+    """:32 `torch.exp(model.z_prior.log_sigma)` (no clamp), evaluated on the host by the
+    library's deterministic exp (float32 of the float64 value) so that an encoder and a decoder
+    on different machines build the same z tables; returned on the model's device."""
+    L = _lib.load()
+    ls = model.z_prior.log_sigma.detach()
+    vals = np.array([L.dsic_host_exp_f32(float(v)) for v in ls.cpu().numpy().astype(np.float32).ravel()],
+                    dtype=np.float32)
+    return torch.from_numpy(vals).to(ls.device)
 
 
 def latent_support(y_tilde, z_tilde, tail=10):
@@ -147,7 +171,7 @@ class AsyncCompressor:
     def __call__(self, partial):
         main = torch.cuda.current_stream()
         if self._sigma_z is None:
-            self._sigma_z = torch.exp(self.model.z_prior.log_sigma).contiguous()
+            self._sigma_z = sigma_z_of(self.model)
             self._sigma_z.record_stream(self.stream)
         ready = torch.cuda.Event()
         ready.record(main)
@@ -186,7 +210,7 @@ def custom_compress(model, x, tail=10, Lmax=DEFAULT_LMAX):
     """eval_selfcontained_entropy.py:26-74.  Returns the reference's dict:
     strings [[z_bytes, y_bytes], ...], shape_y, shape_z, min_y, max_y, min_z, max_z."""
     out = model(x, quant_mode="round")
-    sigma_z = torch.exp(model.z_prior.log_sigma)                       # :32 (no clamp)
+    sigma_z = sigma_z_of(model)                                        # :32 (no clamp)
     if getattr(model, "spatial_params", False):
         # one table row per latent element: size the rows to the actual support (the reference
         # reads min/max on the host here too, :39-40,52-53)
@@ -243,7 +267,7 @@ def custom_decompress(model, compressed, Lmax=None):
     meta = torch.from_numpy(meta_np).to(dev)
     err = torch.zeros(1, dtype=torch.int32, device=dev)
     L = _lib.load()
-    sigma_z = torch.exp(model.z_prior.log_sigma).contiguous()
+    sigma_z = sigma_z_of(model)
     tab_z = torch.zeros((B, N, Lmax), dtype=torch.uint16, device=dev)
     _lib.check(L.dsic_cdf_tables_gauss(_p(sigma_z), _p(meta), _p(tab_z), B, N, Lmax, _p(err), _stream()),
                "cdf_tables_gauss")

@@ -71,7 +71,10 @@ SIGNATURES = {
                                   c_int, c_int, _P, _P, _P]),
     "dsic_host_normal_cdf": (ctypes.c_double, [ctypes.c_double]),
     "dsic_host_student_t_cdf": (ctypes.c_double, [ctypes.c_double, ctypes.c_double]),
-    "dsic_host_cdf_table": (c_int, [c_int, ctypes.c_float, ctypes.c_float, c_int, c_int, _P]),
+    "dsic_host_gaussian_cdf_f32": (ctypes.c_float, [ctypes.c_float]),
+    "dsic_host_exp_f32": (ctypes.c_float, [ctypes.c_float]),
+    "dsic_host_pmf_to_uint16_cdf": (c_int, [_P, c_int, c_int, _P]),
+    "dsic_host_cdf_table": (c_int, [c_int, ctypes.c_float, ctypes.c_float, c_int, c_int, _P, _P]),
 }
 
 _lib = None

@@ -296,11 +296,23 @@ int dsic_stream_create_masked(const uint32_t* mask_host, int words,
 int dsic_stream_destroy(void* stream);
 
 /* The table math evaluated on the HOST (no GPU needed): lets CPU-only tests
- * compare it bit for bit with the oracle.  out_host: L uint16 in host memory. */
+ * compare it bit for bit with the oracle and with the reference-generated
+ * fixture tests/golden/entropy_ref.npz.
+ * dsic_host_gaussian_cdf_f32: eval_selfcontained_entropy.py:14-15 in float32.
+ * dsic_host_pmf_to_uint16_cdf: :17-23; pmf_host [L][C] float32 (support axis
+ *   first), out_host [L+1][C] uint16.
+ * dsic_host_cdf_table: one coder table (:41-47 or :54-61 + spreading);
+ *   out_host: L uint16; raw_host: NULL or L+1 uint16 = the pre-spreading cdf of :22. */
 double dsic_host_normal_cdf(double x);
 double dsic_host_student_t_cdf(double t, double nu);
+float dsic_host_gaussian_cdf_f32(float x);
+/* sigma_z = exp(z_prior.log_sigma) (:32) as float32(exp64(x)): one value for encoder and
+ * decoder on any machine (torch's expf differs between its CPU and GPU builds). */
+float dsic_host_exp_f32(float x);
+int dsic_host_pmf_to_uint16_cdf(const float* pmf_host, int L, int C,
+                                uint16_t* out_host);
 int dsic_host_cdf_table(int student, float sigma, float nu, int smin, int L,
-                        uint16_t* out_host);
+                        uint16_t* out_host, uint16_t* raw_host);
 
 #ifdef __cplusplus
 }

@@ -1,8 +1,9 @@
 """ORACLE (test infrastructure): ctypes front end of oracle/entropy_ref.c plus the
 per-image compress/decompress flow of eval_selfcontained_entropy.py:26-123
 restated on numpy arrays.  See the header of entropy_ref.c for the parity
-status (unpinned: the reference script cannot execute) and the frozen
-interpretation choices."""
+status (z tables pinned by tests/golden/entropy_ref.npz; Student-t tables and
+coded bytes unpinned: that part of the reference cannot execute) and the
+frozen interpretation choices."""
 from __future__ import annotations
 
 import ctypes
@@ -30,9 +31,18 @@ def lib():
         L.ora_student_t_cdf.argtypes = [d, d]
         vp, i, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
         L.ora_tables_gauss.restype = None
-        L.ora_tables_gauss.argtypes = [vp, i, i, i, vp, vp]
+        L.ora_tables_gauss.argtypes = [vp, i, i, i, vp, vp, vp]
         L.ora_tables_student.restype = None
-        L.ora_tables_student.argtypes = [vp, vp, i, i, i, vp, vp]
+        L.ora_tables_student.argtypes = [vp, vp, i, i, i, vp, vp, vp]
+        f = ctypes.c_float
+        L.ora_erff.restype = f
+        L.ora_erff.argtypes = [f]
+        L.ora_gaussian_cdf_f32.restype = f
+        L.ora_gaussian_cdf_f32.argtypes = [f]
+        L.ora_sum_f32.restype = f
+        L.ora_sum_f32.argtypes = [vp, i]
+        L.ora_pmf_to_uint16_cdf.restype = None
+        L.ora_pmf_to_uint16_cdf.argtypes = [vp, i, vp]
         L.ora_range_encode.restype = i64
         L.ora_range_encode.argtypes = [vp, i64, vp, i, i, vp, i64]
         L.ora_range_decode.restype = None
@@ -56,23 +66,51 @@ def student_t_cdf(t, nu):
     return np.array([L.ora_student_t_cdf(float(a), float(b)) for a, b in zip(t.ravel(), nu.ravel())]).reshape(t.shape)
 
 
-def tables_gauss(sigma, smin, L):
+def gaussian_cdf_f32(x):
+    """eval_selfcontained_entropy.py:14-15 evaluated in float32 (x float32 array)."""
+    L = lib()
+    x = np.asarray(x, dtype=np.float32)
+    return np.array([L.ora_gaussian_cdf_f32(float(v)) for v in x.ravel()], dtype=np.float32).reshape(x.shape)
+
+
+def sum_f32(p):
+    """torch.sum(dim=0) order for one float32 column."""
+    p = np.ascontiguousarray(p, dtype=np.float32)
+    return np.float32(lib().ora_sum_f32(_ptr(p), p.size))
+
+
+def pmf_to_uint16_cdf(pmf):
+    """:17-23; pmf [L, C] float32 -> uint16 [L+1, C]."""
+    pmf = np.asarray(pmf, dtype=np.float32)
+    L, C = pmf.shape
+    out = np.empty((C, L + 1), dtype=np.uint16)
+    cols = np.ascontiguousarray(pmf.T)
+    for c in range(C):
+        lib().ora_pmf_to_uint16_cdf(_ptr(cols[c]), L, _ptr(out[c]))
+    return np.ascontiguousarray(out.T)
+
+
+def tables_gauss(sigma, smin, L, raw=False):
+    """coder tables [C, L]; raw=True also returns the pre-spreading uint16 cdf [C, L+1] of :22."""
     sigma = np.ascontiguousarray(sigma, dtype=np.float32)
     C = sigma.size
     out = np.empty((C, L), dtype=np.uint16)
-    work = np.empty(2 * L + 2, dtype=np.float64)
-    lib().ora_tables_gauss(_ptr(sigma), C, int(smin), int(L), _ptr(out), _ptr(work))
-    return out
+    r = np.empty((C, L + 1), dtype=np.uint16) if raw else None
+    work = np.empty(3 * L + 4, dtype=np.float32)
+    lib().ora_tables_gauss(_ptr(sigma), C, int(smin), int(L), _ptr(out), _ptr(r) if raw else None, _ptr(work))
+    return (out, r) if raw else out
 
 
-def tables_student(sigma, nu, smin, L):
+def tables_student(sigma, nu, smin, L, raw=False):
     sigma = np.ascontiguousarray(sigma, dtype=np.float32)
     nu = np.ascontiguousarray(nu, dtype=np.float32)
     C = sigma.size
     out = np.empty((C, L), dtype=np.uint16)
-    work = np.empty(2 * L + 2, dtype=np.float64)
-    lib().ora_tables_student(_ptr(sigma), _ptr(nu), C, int(smin), int(L), _ptr(out), _ptr(work))
-    return out
+    r = np.empty((C, L + 1), dtype=np.uint16) if raw else None
+    work = np.empty(3 * L + 4, dtype=np.float32)
+    lib().ora_tables_student(_ptr(sigma), _ptr(nu), C, int(smin), int(L), _ptr(out),
+                             _ptr(r) if raw else None, _ptr(work))
+    return (out, r) if raw else out
 
 
 def range_encode(sym, tables, hw):

@@ -23,7 +23,8 @@ def _oracle_inputs(out, model):
     z = out["z_tilde"].cpu().numpy()
     sy = out["sigma"][:, :, 0, 0].cpu().numpy()
     ny = out["nu"][:, :, 0, 0].cpu().numpy()
-    sz = torch.exp(model.z_prior.log_sigma).cpu().numpy()
+    from dsic_amd import entropy
+    sz = entropy.sigma_z_of(model).cpu().numpy()
     return y, z, sy, ny, sz
 
 
@@ -66,13 +67,45 @@ def test_device_tables_equal_oracle(model):
         assert m[b, 0] == int(y[b].min()) - 10 and m[b, 1] == int(y[b].max() - y[b].min()) + 21
         assert m[b, 2] == int(z[b].min()) - 10 and m[b, 3] == int(z[b].max() - z[b].min()) + 21
     tab_y, tab_z, err = entropy.cdf_tables(out["sigma"][:, :, 0, 0].contiguous(), out["nu"][:, :, 0, 0].contiguous(),
-                                           torch.exp(model.z_prior.log_sigma), meta, 128)
+                                           entropy.sigma_z_of(model), meta, 128)
     assert int(err.item()) == 0
     ty, tz = tab_y.cpu().numpy(), tab_z.cpu().numpy()
     for b in range(2):
         Ly, Lz = int(m[b, 1]), int(m[b, 3])
         assert np.array_equal(ty[b, :, :Ly], E.tables_student(sy[b], ny[b], int(m[b, 0]), Ly))
         assert np.array_equal(tz[b, :, :Lz], E.tables_gauss(sz, int(m[b, 2]), Lz))
+
+
+def test_device_z_tables_vs_reference_fixture():
+    """The device tables_kernel on the reference's own z cases (tests/golden/entropy_ref.npz, made by
+    running eval_selfcontained_entropy.py:36-48): identical to the oracle, and equal to the reference's
+    uint16 tables (after the documented spreading) except for erf's last bit: max |diff| 1 on < 0.1 %."""
+    import os
+    from dsic_amd import entropy
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "entropy_ref.npz"))
+    total = bad = 0
+    for i in list(range(0, int(g["zsweep/count"][0]), 3)) + [35]:
+        sig, zt, ref = g[f"zsweep/{i}/sigma_z"], g[f"zsweep/{i}/z_tilde"], g[f"zsweep/{i}/cdf_u16"]
+        zmin, Ls = int(zt.min()) - 10, ref.shape[0] - 1
+        Lmax = (Ls + 7) // 8 * 8
+        meta = torch.tensor([[0, 1, zmin, Ls]], dtype=torch.int32, device="cuda")
+        tab_y, tab_z, err = entropy.cdf_tables(torch.ones((1, 1), device="cuda"), torch.full((1, 1), 3.0, device="cuda"),
+                                               torch.from_numpy(sig).cuda(), meta, Lmax)
+        assert int(err.item()) == 0
+        got = tab_z[0, :, :Ls].cpu().numpy().astype(np.int64)
+        assert np.array_equal(got, E.tables_gauss(sig, zmin, Ls))
+        k = np.arange(Ls)[None, :]
+        want = ref[:Ls].T.astype(np.int64) * (65536 - Ls) // 65535 + k          # spreading of DESIGN.md §4
+        b = (np.float32(zmin) - np.float32(0.5)) / sig
+        e = (np.float32(zmin + Ls) - np.float32(0.5)) / sig
+        from scipy import special
+        ok = 0.5 * (special.erf(e / np.sqrt(2.0)) - special.erf(b / np.sqrt(2.0))) > 0.5
+        d = np.abs(got - want)[ok]
+        if d.size:
+            assert d.max() <= 1
+        bad += np.count_nonzero(d)
+        total += d.size
+    assert total > 50000 and bad <= 0.001 * total, (bad, total)
 
 
 @pytest.mark.parametrize("case", ["random", "peaky", "runs", "single"])
@@ -194,7 +227,7 @@ def test_spatial_params_model_and_entropy_path():
     # entropy path on the GPU's own (y, z, sigma, nu): bytes identical to the oracle, exact round trip
     y, z = out["y_tilde"].cpu().numpy(), out["z_tilde"].cpu().numpy()
     sy, ny = out["sigma"].cpu().numpy(), out["nu"].cpu().numpy()
-    sz = torch.exp(m.z_prior.log_sigma).cpu().numpy()
+    sz = entropy.sigma_z_of(m).cpu().numpy()
     want = E.compress(y, z, sy, ny, sz, tail=10)
     got = entropy.custom_compress(m, x.cuda(), tail=10)
     for b in range(2):

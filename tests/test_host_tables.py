@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(L):
     assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.dsic_abi_version() == 1
+    assert L.dsic_abi_version() == 2
 
 
 def test_argument_validation_without_gpu(L):
@@ -57,8 +57,71 @@ def test_host_tables_equal_oracle():
         Lsym = int(rng.integers(21, 90))
         for student in (0, 1):
             out = np.zeros(Lsym, dtype=np.uint16)
+            raw = np.zeros(Lsym + 1, dtype=np.uint16)
             assert Lh.dsic_host_cdf_table(student, float(sig), float(nu), smin, Lsym,
-                                          out.ctypes.data_as(ctypes.c_void_p)) == 0
-            want = (E.tables_student(np.array([sig]), np.array([nu]), smin, Lsym) if student
-                    else E.tables_gauss(np.array([sig]), smin, Lsym))[0]
-            assert np.array_equal(out, want)
+                                          out.ctypes.data_as(ctypes.c_void_p),
+                                          raw.ctypes.data_as(ctypes.c_void_p)) == 0
+            want, want_raw = (E.tables_student(np.array([sig]), np.array([nu]), smin, Lsym, raw=True) if student
+                              else E.tables_gauss(np.array([sig]), smin, Lsym, raw=True))
+            assert np.array_equal(out, want[0]) and np.array_equal(raw, want_raw[0])
+
+
+# ---- the product's host table math against the REFERENCE-generated fixture ------------------
+GOLD = os.path.join(ROOT, "tests", "golden", "entropy_ref.npz")
+
+
+def test_product_pmf_to_uint16_cdf_reproduces_the_reference():
+    """eval_selfcontained_entropy.py:17-23, outputs of the reference's own function."""
+    from dsic_amd import entropy
+    g = np.load(GOLD)
+    for i in range(int(g["u16cdf/count"][0])):
+        got = entropy.pmf_to_uint16_cdf(g[f"u16cdf/{i}/pmf"])
+        assert got.dtype == np.uint16 and np.array_equal(got, g[f"u16cdf/{i}/out"]), i
+
+
+def test_product_gaussian_cdf_vs_reference():
+    from dsic_amd import entropy
+    g = np.load(GOLD)
+    x, want = g["gcdf/x"], g["gcdf/y"]
+    got = entropy.gaussian_cdf(x)
+    assert got.dtype == np.float32
+    assert np.array_equal(got.view(np.uint32), E.gaussian_cdf_f32(x).view(np.uint32))    # host == oracle bits
+    assert np.max(np.abs(got.astype(np.float64) - want)) <= 2.0 ** -24                 # erf's last bit
+    assert np.count_nonzero(got != want) <= 0.03 * x.size
+
+
+def test_product_z_tables_vs_reference(L):
+    """Pre-spreading uint16 tables of the reference's z flow (:36-47): max |diff| 1 on < 0.1 % of
+    the entries (erf's last bit, see tests/test_oracle_entropy.py), identical to the oracle."""
+    g = np.load(GOLD)
+    total = bad = 0
+    for i in range(int(g["zmodel/count"][0])):
+        sig, ref = g[f"zmodel/{i}/sigma_z"], g[f"zmodel/{i}/cdf_u16"]
+        zmin, Ls = int(g[f"zmodel/{i}/zmin"][0]), ref.shape[0] - 1
+        _, oraw = E.tables_gauss(sig, zmin, Ls, raw=True)
+        for c in range(sig.size):
+            out = np.zeros(Ls, dtype=np.uint16)
+            raw = np.zeros(Ls + 1, dtype=np.uint16)
+            assert L.dsic_host_cdf_table(0, float(sig[c]), 0.0, zmin, Ls, out.ctypes.data_as(ctypes.c_void_p),
+                                         raw.ctypes.data_as(ctypes.c_void_p)) == 0
+            assert np.array_equal(raw, oraw[c])
+            d = np.abs(raw.astype(np.int64) - ref[:, c].astype(np.int64))
+            assert d.max() <= 1
+            bad += np.count_nonzero(d)
+            total += d.size
+    assert bad <= 0.001 * total, (bad, total)
+
+
+def test_sigma_z_is_deterministic_and_within_one_ulp_of_torch(L):
+    """:32 sigma_z = exp(log_sigma): the library's float32(exp64) against the reference's CPU torch
+    values (MKL VML vsExp, < 1 ulp)."""
+    g = np.load(GOLD)
+    n = diff = 0
+    for i in range(int(g["zsweep/count"][0])):
+        ls, want = g[f"zsweep/{i}/log_sigma"], g[f"zsweep/{i}/sigma_z"]
+        got = np.array([L.dsic_host_exp_f32(float(v)) for v in ls], dtype=np.float32)
+        assert np.all(np.abs(got.astype(np.float64) - want) <= np.spacing(want))
+        assert np.array_equal(got, np.exp(ls.astype(np.float64)).astype(np.float32))     # correctly rounded
+        diff += np.count_nonzero(got != want)
+        n += ls.size
+    assert diff <= 0.02 * n, (diff, n)
