@@ -5,9 +5,12 @@
 
 One "step" = one pass of the hot path over one batch of B synthetic patches per
 GPU (inputs resident in HBM before the timed region): analysis -> hyper-analysis
--> round -> hyper-synthesis -> Student-t/Gaussian rate -> synthesis, per-image
-bpp (+ MS-SSIM when metrics are built), then the cross-GPU all-reduce of the
-metric sums.  Prints ONE JSON line on rank 0 (contract in the task statement).
+-> round -> hyper-synthesis -> Student-t/Gaussian rate -> CDF tables + range
+coder of the z,y strings (second stream) -> synthesis, per-image bpp + MS-SSIM,
+then the cross-GPU all-reduce of the metric sums: BASELINE.json config 3, the
+largest single-GPU configuration (`--no-entropy` drops the coder: config 2;
+`--size 512 --channels 4 --batch 32` is the per-GPU shape of config 5).
+Prints ONE JSON line on rank 0 (contract in the task statement).
 
 For N > 1 the driver launches this file with torch.distributed.run, one rank
 per GPU; images are sharded by global index, there is no data-path collective.
@@ -30,22 +33,51 @@ PEAK_HBM_GBS = 8000.0
 
 
 class KernelTimer:
-    """HIP-event pairs around chosen launches on the launching stream."""
+    """HIP-event pairs around chosen launches on the launching stream.
+
+    Events come from a pool that is created AND first recorded during warm-up: creating a HIP
+    event costs host time (the first record of a torch event calls hipEventCreate), which would
+    otherwise stall the enqueue thread inside the timed region."""
 
     def __init__(self):
         self.enabled = False
         self.records = []
+        self.pool = []
+        self.used = 0
+
+    def _event(self):
+        if self.used == len(self.pool):
+            self.pool.append(torch.cuda.Event(enable_timing=True))
+        e = self.pool[self.used]
+        self.used += 1
+        return e
+
+    def reserve(self, n):
+        """make sure n events exist and have been recorded once (forces hipEventCreate)"""
+        while len(self.pool) < n:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.pool.append(e)
+
+    def reset(self):
+        self.records = []
+        self.used = 0
 
     def record(self, name, flops, launch, exec_flops):
         if not self.enabled:
             return launch()
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
+        e0, e1 = self._event(), self._event()
         e0.record()
         r = launch()
         e1.record()
         self.records.append((name, flops, e0, e1, exec_flops))
         return r
+
+    def mark(self):
+        """one event on the current stream (step boundaries)"""
+        e = self._event()
+        e.record()
+        return e
 
     def summary(self):
         agg = {}
@@ -58,21 +90,34 @@ class KernelTimer:
         return agg
 
 
-def cpu_baseline(sd, patches, H, W, threads):
-    """Oracle (eager fp32 restatement of the reference forward) on the host cores:
-    one image per call like modelseval.py:158-173."""
-    from oracle import ref_model as O
+def cpu_baseline(sd, patches, H, W, threads, with_coder, budget_s):
+    """The oracle on the host cores, one image per call like modelseval.py:158-173: eager fp32
+    forward (oracle/ref_model.py) + bpp + MS-SSIM[.3,.5,.2] (oracle/ref_metrics.py,
+    modelseval.py:78-94) and, for config 3, the per-image tables + range coder of
+    eval_selfcontained_entropy.py:36-62 (oracle/entropy_ref.c).  -> (images/s, images timed)."""
+    from oracle import entropy_ref as E, ref_metrics as RM, ref_model as O
     torch.set_num_threads(threads)
     imgs = [torch.from_numpy(patches[i:i + 1]) for i in range(min(4, len(patches)))]
-    for i in range(2):
-        O.forward(sd, imgs[i % len(imgs)], "round")
+    sigma_z = np.exp(sd["z_prior.log_sigma"].astype(np.float64)).astype(np.float32)
+
+    def one(x):
+        out = O.forward(sd, x, "round")
+        bpp = float((out["nll_y"].sum() + out["nll_z"].sum()) / (H * W))
+        ms = float(RM.ms_ssim(out["x_hat"].clamp(0, 1), x, data_range=1.0, weights=(0.3, 0.5, 0.2)))
+        nbytes = 0
+        if with_coder:
+            c = E.compress(out["y_tilde"].numpy(), out["z_tilde"].numpy(), out["sigma"][:, :, 0, 0].numpy(),
+                           out["nu"][:, :, 0, 0].numpy(), sigma_z, tail=10)
+            nbytes = sum(len(b) for b in c["strings"][0])
+        return bpp, ms, nbytes
+
+    one(imgs[0])
     times = []
     n = 0
     t_start = time.perf_counter()
-    while n < 12 and time.perf_counter() - t_start < 25.0:
+    while n < 12 and (n < 2 or time.perf_counter() - t_start < budget_s):
         t0 = time.perf_counter()
-        out = O.forward(sd, imgs[n % len(imgs)], "round")
-        float((out["nll_y"].sum() + out["nll_z"].sum()) / (H * W))
+        one(imgs[n % len(imgs)])
         times.append(time.perf_counter() - t0)
         n += 1
     return 1.0 / float(np.median(times)), n
@@ -90,11 +135,11 @@ def main():
     ap.add_argument("--kernels", action="store_true", help="also print the per-kernel event timings to stderr")
     ap.add_argument("--coder-cus", type=int, default=0,
                     help="CUs reserved for the range coder's stream (0 = no CU masking)")
-    ap.add_argument("--entropy", action="store_true",
-                    help="BASELINE config 3: also build the CDF tables and range-code the z,y strings on the "
-                         "GPU (second stream); default is config 2 (transforms + rate + metrics)")
+    ap.add_argument("--no-entropy", action="store_true",
+                    help="BASELINE config 2 (transforms + rate + metrics only).  The default is config 3: the "
+                         "CDF tables and the range coder of the z,y strings also run on the GPU (second stream)")
+    ap.add_argument("--entropy", action="store_true", help="(default; kept for older command lines)")
     args = ap.parse_args()
-    args.no_entropy = not args.entropy
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -132,6 +177,7 @@ def main():
             coder = entropy.AsyncCompressor(model, stream=side, streams_per_wg=8)
         else:
             coder = entropy.AsyncCompressor(model)
+        coder.timing = True
     torch.cuda.set_stream(main_stream)
     count = torch.tensor(float(B), dtype=torch.float64, device=dev)
     zero = torch.zeros((), dtype=torch.float64, device=dev)
@@ -158,17 +204,27 @@ def main():
         totals.copy_(t)
         return out
 
-    for _ in range(args.warmup):
-        step()
-
     def barrier():
         D.barrier()
         torch.cuda.synchronize()
 
+    # warm-up; its last step runs with the kernel timer on so that the event pool (and the coder's)
+    # exists before the clock starts
+    for i in range(args.warmup):
+        timer.enabled = i == args.warmup - 1
+        step()
+    timer.enabled = False
+    per_step = timer.used + 1
+    timer.reserve(per_step * args.steps + 8)
+    if coder is not None:
+        coder.reserve_events(args.steps + 1)
+    timer.reset()
     barrier()
     timer.enabled = True
+    marks = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        marks.append(timer.mark())
         step()
     if coder is not None:
         last = coder.wait()                                      # strings of the final step
@@ -188,22 +244,46 @@ def main():
     if rank == 0:
         agg = timer.summary()
         if args.kernels:
-            for k, (c, t, f, x) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            print("step periods (ms, step-start events on the main stream): "
+                  + " ".join(f"{a.elapsed_time(b):.2f}" for a, b in zip(marks, marks[1:])), file=sys.stderr)
+            for k, (c, t, f, ex) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 print(f"{k:40s} {c:5d} launches {t / args.steps * 1e3:8.3f} ms/step  {f / t / 1e12:7.1f} TF/s algorithmic "
-                      f"{x / t / 1e12:7.1f} executed", file=sys.stderr)
+                      f"{ex / t / 1e12:7.1f} executed", file=sys.stderr)
         name, (cnt, secs, flops, exflops) = max(agg.items(), key=lambda kv: kv[1][1])
-        achieved = flops / secs / 1e12
+        executed = exflops / secs / 1e12
+        algorithmic = flops / secs / 1e12
         conv_secs = sum(v[1] for v in agg.values())
-        pmc = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path):
-            with open(pmc_path) as f:
-                pmc = json.load(f).get(name)
-        mfma_pmc = None
-        mfma_path = os.path.join(ROOT, "profiles", "round1_mfma_util.json")
-        if os.path.exists(mfma_path):
-            with open(mfma_path) as f:
-                mfma_pmc = (json.load(f).get(name) or {}).get("mfma_util")
+
+        def from_profile(fname, key=None):
+            """Numbers of a SEPARATE rocprofv3 --pmc pass, committed under profiles/ (not measured by
+            this invocation): returned with the file they come from, or (None, None)."""
+            path = os.path.join(ROOT, "profiles", fname)
+            if not os.path.exists(path):
+                return None, None
+            with open(path) as f:
+                d = json.load(f)
+            v = d.get(name)
+            if key is not None and isinstance(v, dict):
+                v = v.get(key)
+            return v, f"profiles/{fname}" + (f" (commit {d['_commit']})" if "_commit" in d else "")
+
+        traffic, traffic_src = from_profile("pmc_traffic.json")
+        mfma_pmc, mfma_src = from_profile("mfma_util.json", "mfma_util")
+        if (H, W, C) != (256, 256, 3):
+            traffic = traffic_src = mfma_pmc = mfma_src = None      # the committed PMC passes are 256x256x3
+        coder_stats = None
+        if coder is not None and coder.times:
+            ms = [e0.elapsed_time(e1) for e0, e1 in coder.times[-args.steps:]]
+            n_sym = B * (model.M * (H // 16) * (W // 16) + model.N * (H // 64) * (W // 64))
+            coded_bytes = float(tot[3] / n_img) * H * W / 8.0 * B
+            coder_stats = {
+                "ms_per_batch": float(np.mean(ms)),
+                "symbols_per_s": n_sym / (float(np.mean(ms)) * 1e-3),
+                "string_bytes_per_s": coded_bytes / (float(np.mean(ms)) * 1e-3),
+                "symbols_per_batch": n_sym,
+                "note": "support scan + CDF tables + range encoder of one batch on the side stream, HIP events "
+                        "on that stream, while the main stream runs synthesis / MS-SSIM / the next analysis",
+            }
         res = {
             "metric": "256x256 satellite patches encoded/s per GPU; bpp + MS-SSIM vs reference",
             "value": value,
@@ -221,7 +301,8 @@ def main():
                 "workload": f"batch={B}/GPU {H}x{W}x{C} synthetic patches, modelv2 encode->decode "
                             "(g_a,h_a,round,h_s,Student-t/Gaussian rate,g_s) + bpp + MS-SSIM[.3,.5,.2] on GPU"
                             + (" [BASELINE config 2]" if args.no_entropy else
-                               " + CDF tables and range coder (z,y strings) on GPU [BASELINE config 3]"),
+                               " + CDF tables and range coder (z,y strings) on GPU [BASELINE config 3]")
+                            + ("" if (H, W, C) == (256, 256, 3) else " [shape of BASELINE config 5]"),
                 "global_batch": B * world,
                 "parallelism": f"per-image sharding x{world}, one all-reduce of 4 fp64",
                 "weights": "synthetic seed 1 (checkpoints absent from the reference)",
@@ -230,38 +311,46 @@ def main():
             "mean_ms_ssim": float(tot[1] / n_img),
             "mean_bpp_coded": (float(tot[3] / n_img) if not args.no_entropy else None),
             "images_per_s_per_gpu": value / world,
+            "coder": coder_stats,
             "roofline": {
                 "bound": "mfma",
                 "kernel": name,
                 "launches": cnt,
                 "avg_launch_ms": secs / cnt * 1e3,
-                "achieved": achieved,
+                # FLOPs the kernel's algorithm executes on the MFMA pipe (Winograd F(2x2,3x3) with
+                # zero-position skipping: 12.25 of every 25 direct-convolution MACs of a 5x5/s2
+                # layer) / its HIP-event time; frac <= 1 by construction
+                "achieved": executed,
                 "peak": PEAK_FP32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": pmc,
-                # `achieved` counts ALGORITHMIC (direct-convolution) FLOPs; the
-                # Winograd kernel executes 2.25x (3x3) / 1.56x (5x5 s2) fewer on the MFMA pipe:
-                "executed": exflops / secs / 1e12,
-                "executed_frac": exflops / secs / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x SIMDs) of the same kernel from a separate
-                # rocprofv3 --pmc pass (profiles/round1_mfma_util.json): per clock actually run, not per 2.4 GHz
+                "frac": executed / PEAK_FP32_MFMA_TFLOPS,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
+                # direct-convolution FLOP count of SURVEY.md §8(d) / the same time: may exceed the
+                # peak because Winograd executes fewer multiplies; not a roofline fraction
+                "algorithmic_tflops": algorithmic,
+                "algorithmic_over_direct_peak": algorithmic / PEAK_FP32_MFMA_TFLOPS,
                 "mfma_busy_pmc": mfma_pmc,
-                "all_conv_tflops": sum(v[2] for v in agg.values()) / conv_secs / 1e12,
+                "mfma_busy_source": mfma_src,
                 "all_conv_executed_tflops": sum(v[3] for v in agg.values()) / conv_secs / 1e12,
+                "all_conv_executed_frac": sum(v[3] for v in agg.values()) / conv_secs / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                "all_conv_algorithmic_tflops": sum(v[2] for v in agg.values()) / conv_secs / 1e12,
                 "conv_share_of_step": conv_secs / elapsed,
             },
         }
-        if world == 1 and not args.no_cpu_baseline and (H, W) == (256, 256):
+        if world == 1 and not args.no_cpu_baseline:
             # the GPU box gives one job a 16-CPU share of a larger host
             cores = min(len(os.sched_getaffinity(0)), 16)
-            v_all, n_all = cpu_baseline(sd, patches, H, W, cores)
-            v_one, n_one = cpu_baseline(sd, patches, H, W, 1)
+            with_coder = not args.no_entropy
+            v_all, n_all = cpu_baseline(sd, patches, H, W, cores, with_coder, 14.0)
+            v_one, n_one = cpu_baseline(sd, patches, H, W, 1, with_coder, 14.0)
             res["cpu_baseline"] = {
                 "value": v_all, "unit": "images/s", "cores": cores, "kind": "port",
-                "sample": f"{n_all} single-image eager-fp32 forwards (oracle/ref_model.py, verified against the "
-                          f"reference in the build container) + bpp, median; 1 thread: {v_one:.3f} images/s "
-                          f"over {n_one} images (cpu.sbatch:5 requests 1 CPU)",
+                "sample": f"{n_all} single-image calls of the oracle (eager-fp32 forward of oracle/ref_model.py, "
+                          "verified against the imported reference in the build container, + bpp + "
+                          "MS-SSIM[.3,.5,.2]" + (" + per-image CDF tables and range coder of oracle/entropy_ref.c"
+                                                  if with_coder else "")
+                          + f"), median; 1 thread: {v_one:.3f} images/s over {n_one} images (cpu.sbatch:5 requests 1 CPU)",
                 "value_1thread": v_one,
             }
         print(json.dumps(res))

@@ -167,23 +167,49 @@ class AsyncCompressor:
         self.stream = stream if stream is not None else torch.cuda.Stream()
         self.last = None
         self._sigma_z = None
+        self.timing = False          # bench.py: keep a HIP-event pair per call on the coder's stream
+        self.times = []
+        self._events = []            # pre-created timing events (see reserve_events)
+        self._ready = None
+
+    def reserve_events(self, n):
+        """create n (start, done) timing-event pairs now, so that none is created while timing"""
+        with torch.cuda.stream(self.stream):
+            while len(self._events) < n:
+                pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                pair[0].record(self.stream)
+                pair[1].record(self.stream)
+                self._events.append(pair)
+
+    def _pair(self):
+        if self._events:
+            return self._events.pop()
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def __call__(self, partial):
         main = torch.cuda.current_stream()
         if self._sigma_z is None:
             self._sigma_z = sigma_z_of(self.model)
             self._sigma_z.record_stream(self.stream)
-        ready = torch.cuda.Event()
+        if self._ready is None:
+            self._ready = torch.cuda.Event()
+        ready = self._ready              # re-recorded per call; wait_event captures this record
         ready.record(main)
         tensors = [partial["y_tilde"], partial["z_tilde"], partial["sigma"], partial["nu"]]
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ready)
             for t in tensors:
                 t.record_stream(self.stream)      # allocator must not recycle them under the coder
+            if self.timing:
+                e0, done = self._pair()
+                e0.record(self.stream)
+            else:
+                done = torch.cuda.Event()
             self.last = compress_latents(tensors[0], tensors[1], tensors[2], tensors[3], self._sigma_z,
                                          self.tail, self.Lmax, self.streams_per_wg)
-            done = torch.cuda.Event()
             done.record(self.stream)
+            if self.timing:
+                self.times.append((e0, done))
             self.last["done"] = done
 
     def wait(self):

@@ -74,3 +74,46 @@ def test_config5_512x512x4_patch_vs_oracle():
     x2 = torch.from_numpy(S.make_patches(900, 2, 512, 512, 4)).cuda()
     out2 = m(x2, quant_mode="round")
     assert torch.equal(out2["y_tilde"][0], out["y_tilde"][0])
+
+
+def test_config5_per_gpu_batch_32x4x512x512_properties():
+    """BASELINE config 5 at its per-GPU working size (256 patches over 8 GPUs = 32 x 4 x 512 x 512
+    per GPU; 4.3 GB activations): determinism, batch invariance against the B=1 case that
+    test_config5_512x512x4_patch_vs_oracle pins to the oracle, shard equality, encode -> decode."""
+    from dsic_amd import entropy, metrics
+    m = _model(in_ch=4)
+    x = torch.from_numpy(S.make_patches(900, 32, 512, 512, 4)).cuda()
+    out = m(x, quant_mode="round")
+    assert out["y_tilde"].shape == (32, 192, 32, 32) and out["z_tilde"].shape == (32, 128, 8, 8)
+    assert out["x_hat"].shape == (32, 4, 512, 512)
+    out2 = m(x, quant_mode="round")
+    for k in ("x_hat", "y", "z", "nll_y", "nll_z"):
+        assert torch.equal(out[k], out2[k]), k
+    assert torch.equal(out.sums, out2.sums)
+    del out2
+    # image 0 alone is the oracle-checked patch; image 31 alone crosses every 2 GiB offset of the batch
+    for i in (0, 31):
+        solo = m(x[i:i + 1].contiguous(), quant_mode="round")
+        assert torch.equal(solo["y_tilde"][0], out["y_tilde"][i]), i
+        assert torch.equal(solo["z_tilde"][0], out["z_tilde"][i]), i
+        assert torch.equal(solo["x_hat"][0], out["x_hat"][i]), i
+        assert abs(float(solo.sums.sum()) - float(out.sums[i].sum())) < 1e-5 * float(solo.sums.sum())
+    # a shard (second half of the per-GPU batch, generated from its global index) reproduces its slice
+    half = torch.from_numpy(S.make_patches(916, 16, 512, 512, 4)).cuda()
+    assert torch.equal(m(half, quant_mode="round")["y_tilde"], out["y_tilde"][16:])
+    del half
+    assert torch.equal(out["y_tilde"], torch.round(out["y"]))
+    bpp = out.sums.sum(dim=1) / float(512 * 512)
+    assert 1.5 < float(bpp.min()) and float(bpp.max()) < 4.0
+    # encode -> decode: the strings of all 32 patches reproduce x_hat exactly; coded size tracks the estimate
+    c = entropy.custom_compress(m, x)
+    assert c["shape_y"] == [32, 192, 32, 32] and c["shape_z"] == [32, 128, 8, 8]
+    x_hat = entropy.custom_decompress(m, entropy.unpack_container(entropy.pack_container(c)))
+    assert torch.equal(x_hat, out["x_hat"].clamp(0, 1))
+    est_bits = float(out.sums.sum())
+    real_bits = 8.0 * sum(len(s) for e in c["strings"] for s in e)
+    # (the density estimate of model.py:76 is not a code length: for these 4-band latents the
+    # integrated bin mass is ~1.2 % larger than the density at the integer, so the strings are shorter)
+    assert 0.97 * est_bits < real_bits < 1.03 * est_bits
+    ms = metrics.ms_ssim_per_image(out["x_hat"], x, clamp_x=True)
+    assert ms.shape == (32,) and float(ms.min()) > 0.0 and float(ms.max()) < 1.0
