@@ -127,6 +127,57 @@ __device__ __forceinline__ void put_ones(uint32_t* out32, int64_t cap_bits, int6
   }
 }
 
+// ---- fast serial step (full groups of 64 symbols whose c_high < 65536) ------------------------
+// State (low, span) with span = high - low + 1 kept mod 2^32 (0 means 2^32).  The lanes hold
+// c << 16, so floor(span * c / 2^16) is ONE s_mul_hi_u32; the step is unrolled with immediate
+// lane selects (no M0 / wait-state padding), and only (low1, high1) — the interval BEFORE
+// renormalisation — are recorded: which bits became final (E1/E2), how long the E3 run is and
+// what is owed from earlier symbols is recomputed from them by the 64 lanes in parallel.
+// ~22 scalar instructions per symbol instead of ~55.
+template <int J>
+__device__ __forceinline__ void wlane(uint32_t& rec, uint32_t v) {
+  asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(rec) : "s"(v), "n"(J));
+}
+
+template <int J>
+__device__ __forceinline__ void enc_step(uint32_t& low, uint32_t& span, uint32_t clo16, uint32_t chi16,
+                                         uint32_t& rec_low, uint32_t& rec_high) {
+  const uint32_t cl = __builtin_amdgcn_readlane(clo16, J);
+  const uint32_t ch = __builtin_amdgcn_readlane(chi16, J);
+  uint32_t lo_add, hi_add;
+  if (__builtin_expect(span == 0u, 0)) {  // span = 2^32: (2^32 c) >> 16
+    lo_add = cl;
+    hi_add = ch;
+  } else {
+    lo_add = __umulhi(span, cl);
+    hi_add = __umulhi(span, ch);
+  }
+  const uint32_t low1 = low + lo_add;
+  const uint32_t span1 = hi_add - lo_add;        // >= 2^14 - 1
+  const uint32_t high1 = low1 + span1 - 1u;
+  wlane<J>(rec_low, low1);
+  wlane<J>(rec_high, high1);
+  const int nb = __builtin_clz(low1 ^ high1);    // E1/E2
+  const uint32_t q = high1 | ~low1;              // 0 where (low, high) = (1, 0): E3 pairs below the split bit
+  const int m = __builtin_clz((q << nb) << 1);   // != 0: an all-E3 tail would need span1 == 2
+  const int sh = nb + m;
+  low = (low1 << sh) & 0x7FFFFFFFu;
+  span = span1 << sh;                            // exactly 2^32 -> 0
+}
+
+template <int J0>
+__device__ __forceinline__ void enc_steps8(uint32_t& low, uint32_t& span, uint32_t clo16, uint32_t chi16,
+                                           uint32_t& rec_low, uint32_t& rec_high) {
+  enc_step<J0 + 0>(low, span, clo16, chi16, rec_low, rec_high);
+  enc_step<J0 + 1>(low, span, clo16, chi16, rec_low, rec_high);
+  enc_step<J0 + 2>(low, span, clo16, chi16, rec_low, rec_high);
+  enc_step<J0 + 3>(low, span, clo16, chi16, rec_low, rec_high);
+  enc_step<J0 + 4>(low, span, clo16, chi16, rec_low, rec_high);
+  enc_step<J0 + 5>(low, span, clo16, chi16, rec_low, rec_high);
+  enc_step<J0 + 6>(low, span, clo16, chi16, rec_low, rec_high);
+  enc_step<J0 + 7>(low, span, clo16, chi16, rec_low, rec_high);
+}
+
 __global__ __launch_bounds__(1024) void range_encode_kernel(
     const float* __restrict__ y, const float* __restrict__ z, const int* __restrict__ meta,
     const uint16_t* __restrict__ tab_y, const uint16_t* __restrict__ tab_z, int Lmax, int M, int HWy,
@@ -182,42 +233,86 @@ __global__ __launch_bounds__(1024) void range_encode_kernel(
     const float sym2 = sym_of(base + 128 + lane);
     const uint32_t nxt = pair_of(sym1, base + 64 + lane);
     const int cnt = (int)((n - base) < 64 ? (n - base) : 64);
-    uint32_t rec0 = 0, rec1 = 0;  // lane j: (nb << 24 | bits) and the pending count flushed at symbol j
-    for (int j = 0; j < cnt; ++j) {
-      const uint32_t pr = __builtin_amdgcn_readlane(cur, j);
-      const uint32_t c_low = pr & 0xFFFFu, c_high = (pr >> 16) + 1u;
-      // span = high - low + 1 (up to 2^32): (span*c) >> 16 == (r*c + c) >> 16 with r = high - low
-      const uint32_t r = high - low;
-      const uint32_t hi_add = (uint32_t)(((uint64_t)r * c_high + c_high) >> 16);
-      const uint32_t lo_add = (uint32_t)(((uint64_t)r * c_low + c_low) >> 16);
-      high = (low - 1u) + hi_add;
-      low = low + lo_add;
-      // Between symbols high - low >= 2^30 (MSBs differ, no E3 pending) and every table interval
-      // is >= 1/65536, so the new interval is >= 2^14 - 2 wide: low != high, nb <= 18.
-      const int nb = __builtin_clz(low ^ high);             // E1/E2: leading bits now final
-      const uint32_t bits = (low >> 1) >> (31 - nb);        // those nb bits (0 when nb == 0)
-      const uint32_t flush = nb ? pending : 0u;             // inverse bits owed behind the first one
-      pending = nb ? 0u : pending;
-      // v_writelane has no clang builtin on this toolchain.  The lane select goes through M0
-      // (an SGPR value plus an SGPR lane select would exceed the constant-bus limit); s_nop 3:
-      // an SALU result needs 4 wait states before it is used as a lane select, and hipcc pads
-      // nothing inside asm.  The kernel uses no LDS, GWS or movrel, so M0 is otherwise unused.
-      const uint32_t w0 = bits | ((uint32_t)nb << 24);
-      asm volatile("s_mov_b32 m0, %4\n\ts_nop 3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
-                   : "+v"(rec0), "+v"(rec1)
-                   : "s"(w0), "s"(flush), "s"(j));
-      low <<= nb;
-      high = (high << nb) | ((1u << nb) - 1u);
-      // E3: low = 01.., high = 10..: m consecutive (1,0) bit pairs below the MSB
-      const uint32_t e3 = (low << 1) & ~(high << 1);        // bit 0 is 0, so ~e3 != 0
-      const int m = __builtin_clz(~e3);
-      pending += (uint32_t)m;
-      low = (low << m) & 0x7FFFFFFFu;                       // MSB(low) is 0 here, so m == 0 is a no-op
-      high = (high << m) | 0x80000000u | ((1u << m) - 1u);
+    uint32_t nbv, bitsv, pendv;   // lane j: final bits of symbol j, their count, inverse bits owed behind the first
+    const uint32_t c_lo_v = cur & 0xFFFFu, c_hi_v = (cur >> 16) + 1u;
+    if (cnt == 64 && !__any(c_hi_v == 0x10000u)) {
+      // ---- fast path ----
+      uint32_t rec_low = 0, rec_high = 0;
+      uint32_t span = high - low + 1u;
+      const uint32_t clo16 = c_lo_v << 16, chi16 = c_hi_v << 16;
+      enc_steps8<0>(low, span, clo16, chi16, rec_low, rec_high);
+      enc_steps8<8>(low, span, clo16, chi16, rec_low, rec_high);
+      enc_steps8<16>(low, span, clo16, chi16, rec_low, rec_high);
+      enc_steps8<24>(low, span, clo16, chi16, rec_low, rec_high);
+      enc_steps8<32>(low, span, clo16, chi16, rec_low, rec_high);
+      enc_steps8<40>(low, span, clo16, chi16, rec_low, rec_high);
+      enc_steps8<48>(low, span, clo16, chi16, rec_low, rec_high);
+      enc_steps8<56>(low, span, clo16, chi16, rec_low, rec_high);
+      high = low + span - 1u;
+      // lanes: what symbol j emitted
+      nbv = (uint32_t)__builtin_clz(rec_low ^ rec_high);
+      bitsv = nbv ? rec_low >> (32u - nbv) : 0u;
+      const uint32_t mv = (uint32_t)__builtin_clz((((rec_high | ~rec_low) << nbv) << 1) | 1u);
+      // pending count in front of symbol j = sum of the E3 runs since the last symbol that
+      // emitted bits (its own run included), or since the carry-in: a segmented prefix sum
+      uint32_t T = mv;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(T, o, 64);
+        if (lane >= o) T += up;
+      }
+      const uint32_t Tex = T - mv;
+      const uint64_t heads = __ballot(nbv > 0);
+      const uint64_t before = heads & ((1ull << lane) - 1ull);
+      const int hb = 63 - __builtin_clzll(before | 1ull);
+      const uint32_t Tex_h = __shfl(Tex, hb, 64);
+      const uint32_t pend_in = before ? Tex - Tex_h : pending + Tex;
+      pendv = nbv ? pend_in : 0u;
+      const int hl = 63 - __builtin_clzll(heads | 1ull);
+      const uint32_t T63 = __builtin_amdgcn_readlane(T, 63);
+      const uint32_t Tex_hl = __builtin_amdgcn_readlane(Tex, hl);
+      pending = heads ? T63 - Tex_hl : pending + T63;
+    } else {
+      // ---- general path (last partial group, or a symbol whose c_high is 65536) ----
+      uint32_t rec0 = 0, rec1 = 0;  // lane j: (nb << 24 | bits) and the pending count flushed at symbol j
+      for (int j = 0; j < cnt; ++j) {
+        const uint32_t pr = __builtin_amdgcn_readlane(cur, j);
+        const uint32_t c_low = pr & 0xFFFFu, c_high = (pr >> 16) + 1u;
+        // span = high - low + 1 (up to 2^32): (span*c) >> 16 == (r*c + c) >> 16 with r = high - low
+        const uint32_t r = high - low;
+        const uint32_t hi_add = (uint32_t)(((uint64_t)r * c_high + c_high) >> 16);
+        const uint32_t lo_add = (uint32_t)(((uint64_t)r * c_low + c_low) >> 16);
+        high = (low - 1u) + hi_add;
+        low = low + lo_add;
+        // Between symbols high - low >= 2^30 (MSBs differ, no E3 pending) and every table interval
+        // is >= 1/65536, so the new interval is >= 2^14 - 2 wide: low != high, nb <= 18.
+        const int nb = __builtin_clz(low ^ high);             // E1/E2: leading bits now final
+        const uint32_t bits = (low >> 1) >> (31 - nb);        // those nb bits (0 when nb == 0)
+        const uint32_t flush = nb ? pending : 0u;             // inverse bits owed behind the first one
+        pending = nb ? 0u : pending;
+        // v_writelane has no clang builtin on this toolchain.  The lane select goes through M0
+        // (an SGPR value plus an SGPR lane select would exceed the constant-bus limit); s_nop 3:
+        // an SALU result needs 4 wait states before it is used as a lane select, and hipcc pads
+        // nothing inside asm.  The kernel uses no LDS, GWS or movrel, so M0 is otherwise unused.
+        const uint32_t w0 = bits | ((uint32_t)nb << 24);
+        asm volatile("s_mov_b32 m0, %4\n\ts_nop 3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+                     : "+v"(rec0), "+v"(rec1)
+                     : "s"(w0), "s"(flush), "s"(j));
+        low <<= nb;
+        high = (high << nb) | ((1u << nb) - 1u);
+        // E3: low = 01.., high = 10..: m consecutive (1,0) bit pairs below the MSB
+        const uint32_t e3 = (low << 1) & ~(high << 1);        // bit 0 is 0, so ~e3 != 0
+        const int m = __builtin_clz(~e3);
+        pending += (uint32_t)m;
+        low = (low << m) & 0x7FFFFFFFu;                       // MSB(low) is 0 here, so m == 0 is a no-op
+        high = (high << m) | 0x80000000u | ((1u << m) - 1u);
+      }
+      nbv = rec0 >> 24;
+      bitsv = rec0 & 0xFFFFFFu;
+      pendv = rec1;
     }
     // parallel placement of this group's bits
     {
-      const uint32_t nbv = rec0 >> 24, bitsv = rec0 & 0xFFFFFFu, pendv = rec1;
       const uint32_t len = nbv + pendv;
       uint32_t incl = len;
 #pragma unroll
