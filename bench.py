@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--channels", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernels", action="store_true", help="also print the per-kernel event timings to stderr")
+    ap.add_argument("--streams-per-wg", type=int, default=4, help="range-coder waves per workgroup (1..16)")
     ap.add_argument("--coder-cus", type=int, default=0,
                     help="CUs reserved for the range coder's stream (0 = no CU masking)")
     ap.add_argument("--no-entropy", action="store_true",
@@ -176,7 +177,7 @@ def main():
             main_stream, side = entropy.masked_streams(args.coder_cus)
             coder = entropy.AsyncCompressor(model, stream=side, streams_per_wg=8)
         else:
-            coder = entropy.AsyncCompressor(model)
+            coder = entropy.AsyncCompressor(model, streams_per_wg=args.streams_per_wg)
         coder.timing = True
     torch.cuda.set_stream(main_stream)
     count = torch.tensor(float(B), dtype=torch.float64, device=dev)

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void tables_kernel(const float* __restrict__ s
   if (lane == 0) dm::finish_table(F, L, tables + ((size_t)b * C + c) * Lmax, pmf, nullptr);
 }
 
-// Range encoder, one wave per (image, stream): stream id = b*2 + which (0: z string,
+// Range encoder, one wave per (image, stream): stream ids 0..B-1 = y strings, B..2B-1 = z strings (which 0: z string,
 // 1: y string); several streams (one per SIMD) share a workgroup.
 //
 // The coder is split along its only true dependency.  (1) The interval recurrence
@@ -186,7 +186,10 @@ __global__ __launch_bounds__(1024) void range_encode_kernel(
   const int lane = threadIdx.x & 63;
   const int sid = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
   if (sid >= nstreams) return;
-  const int b = sid >> 1, which = sid & 1;
+  // streams 0..B-1 are the long y strings, B..2B-1 the short z strings: the y waves share as few
+  // workgroups (= CUs, which a persistent conv workgroup cannot use meanwhile) as possible
+  const int nimg = nstreams >> 1;
+  const int which = sid < nimg ? 1 : 0, b = which ? sid : sid - nimg;
   const int C = which ? M : N, HW = which ? HWy : HWz;
   const int64_t n = (int64_t)C * HW;
   const float* sym = which ? y + (size_t)b * n : z + (size_t)b * n;
