@@ -1,0 +1,619 @@
+// Winograd F(2x2,3x3) convolution with the 16 position GEMMs on the bf16 MFMA path and fp32-class
+// results: every fp32 operand is split into bf16 planes, x = hi + mid (+ lo), and the products
+// hi*hi, hi*mid, mid*hi (PLANES = 2; + mid*mid, hi*lo, lo*hi for PLANES = 3) are accumulated in
+// fp32 by v_mfma_f32_32x32x16_bf16.  A bf16 x bf16 product is exact in fp32, so the only change
+// against the fp32-MFMA kernel (conv_wino.hip) is the dropped low-order cross terms: relative
+// 2^-16 per product for two planes, 2^-24 for three.  tools/split_bf16_emulation.py runs both on
+// the 9 reference fixtures: two planes <= 1 latent flip per image, |dbpp| <= 1e-5; three planes
+// 0 flips, |dbpp| <= 1e-8.  Same layers as conv_wino.hip: conv(.,.,3,1),
+// conv(C,C,5,2) over space-to-depth, ConvTranspose2d(.,.,5,2,2,1) as four phases
+// (code/modelv2/layers.py:54-72, 83-97, 108-124); same fused bias + GDN/IGDN/ReLU epilogue.
+//
+// The bf16 MFMA runs at 16x the fp32-input rate, so three of them per k-step are 5.3x less matrix
+// time; what the workgroup must now feed is what shapes the kernel:
+//   * chunks of 16 input channels (one MFMA k-step); V planes [plane][pos 16][tile 32][16 bf16],
+//     32-byte rows with the 16-byte k-block XOR-swizzled by (tile>>3)&1 (conflict-free
+//     ds_read_b128), double buffered: 64 KB.  The outputs get their own LDS region (72 KB), so the
+//     V buffers never wait for the copy-out.
+//   * 768 threads = 8 MFMA waves + 4 helper waves, as in conv_wino.hip.  MFMA wave (nt, ph) owns
+//     32 output channels x 8 positions (128 accumulator VGPRs); per chunk and position it reads
+//     the two V planes (2 ds_read_b128), takes the two U planes from its register ring
+//     (transformed weights, bf16, [pos][chunk][plane][CoutP][16], streamed from L2) and issues
+//     3 MFMAs.
+//   * the helpers form two groups (waves 8,9 / 10,11): group g loads, transforms (B^T d B in fp32),
+//     splits and stores the chunks of parity g into V buffer g while the MFMA waves consume the
+//     other buffer, and is idle (copying finished outputs to HBM) during the next chunk.
+// Tile hand-out, the fold through LDS and the fused epilogue are those of conv_wino.hip.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+#ifndef WB_PLANES
+#define WB_PLANES 2
+#endif
+
+namespace dsic {
+namespace wb {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef int intx4 __attribute__((ext_vector_type(4)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct Args {
+  const float* in;
+  const void* u;  // bf16 planes [phase][16 pos][Cin/16][PLANES][CoutP][16]
+  const float* bias;
+  const float* beta;
+  const float* gamma;
+  float* out;
+  int B, H, W, Cin, Cout, CoutP;
+  int act;
+  unsigned long long* ticket;
+  int nphase;
+  int64_t u_phase_bytes;
+  int s2d_in, s2d;
+  int tiles_x, tiles_y, ntiles;
+  int nt_out;
+};
+
+constexpr int P = WB_PLANES;
+constexpr int CK = 16;                          // channels per chunk = one MFMA k-step
+constexpr int ROWB = CK * 2;                    // bytes per (pos, tile) row of a plane
+constexpr int POSB = 32 * ROWB;                 // bytes per position of a plane
+constexpr int PLANEB = 16 * POSB;               // 16384
+constexpr int VBUFB = P * PLANEB;               // bytes per V buffer
+constexpr int WP = 36;                          // floats per (plane, tile) row of the output region
+constexpr int YOFF = 2 * VBUFB;                 // byte offset of the output region
+constexpr int YBYTES = 16 * 32 * WP * 4;        // 73728
+constexpr int SLOTOFF = YOFF + YBYTES;
+constexpr int LDS_TOTAL = SLOTOFF + 64;
+constexpr int THREADS = 768;
+constexpr int RING = 2;                         // position-steps of U fragments in flight per MFMA wave
+
+static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
+
+__device__ __forceinline__ floatx2 pk_sub(floatx2 a, floatx2 b) {
+  floatx2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ floatx4 sub4(floatx4 a, floatx4 b) { return a - b; }
+__device__ __forceinline__ floatx16 sub16(floatx16 a, floatx16 b) {
+  floatx16 r;
+#pragma unroll
+  for (int i = 0; i < 16; i += 2) {
+    const floatx2 x = {a[i], a[i + 1]}, y = {b[i], b[i + 1]};
+    const floatx2 d = pk_sub(x, y);
+    r[i] = d[0];
+    r[i + 1] = d[1];
+  }
+  return r;
+}
+
+// two floats -> packed bf16 pair (round to nearest even), and the pair back as two floats
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float bf16_lo(unsigned pk) { return __builtin_bit_cast(float, pk << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned pk) { return __builtin_bit_cast(float, pk & 0xFFFF0000u); }
+
+struct Tile {
+  int item, tx, ty, n;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  float* const yreg = (float*)(lds_raw + YOFF);
+  float* const slots = (float*)(lds_raw + SLOTOFF);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  auto read_slot = [&](int s) {
+    const intx4 v = *(const intx4*)(slots + 4 * s);
+    Tile t;
+    t.item = __builtin_amdgcn_readfirstlane(v[0]);
+    t.tx = __builtin_amdgcn_readfirstlane(v[1]);
+    t.ty = __builtin_amdgcn_readfirstlane(v[2]);
+    t.n = __builtin_amdgcn_readfirstlane(v[3]);
+    return t;
+  };
+  const int pshift = a.nphase == 4 ? 2 : 0;
+  const int nchunks = a.Cin / CK;  // even, >= 4 (host)
+
+  if (wave >= 8) {
+    // =================================== helper waves ===========================================
+    const int ht = tid - 512;
+    const int grp = __builtin_amdgcn_readfirstlane(ht >> 7);  // chunk parity this thread produces
+    const int Cin = a.Cin;
+    // input side: thread = (Winograd tile pt, channel quad pq of the 16-channel chunk)
+    const int t7 = ht & 127;
+    const int pt = t7 >> 2, pq = t7 & 3;
+    const int ptx = pt & 7, pty = pt >> 3;
+    // LDS byte offset of this thread's 8 bytes inside a (plane, pos) block
+    const int vwrite = pt * ROWB + ((((pq >> 1) ^ ((pt >> 3) & 1))) << 4) + ((pq & 1) << 3);
+    unsigned char* const vmine = lds_raw + grp * VBUFB + vwrite;
+    // output side: thread = (Winograd tile ot, channel quad oq of a 32-channel group), all 256 helpers
+    const int ot = ht >> 3, oq = ht & 7;
+    const int otx = ot & 7, oty = ot >> 3;
+    const int yread = ot * WP + 4 * oq;
+    auto post = [&](int s, int item) {  // helper thread 0 only
+      const int tile = item >> pshift;
+      const int row = tile / a.tiles_x;
+      const intx4 v = {item, tile - row * a.tiles_x, row % a.tiles_y, row / a.tiles_y};
+      *(intx4*)(slots + 4 * s) = v;
+    };
+    struct Aim {
+      unsigned off[16];
+      __amdgpu_buffer_rsrc_t rsrc;
+    };
+    auto aim = [&](Aim& m, const Tile& t) {
+      const int gy0 = t.ty * 8 + 2 * pty - 1, gx0 = t.tx * 16 + 2 * ptx - 1;
+      m.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)t.n * a.H * a.W * Cin), 0,
+                                                 a.H * a.W * Cin * 4, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gy = gy0 + i;
+        const bool yok = gy >= 0 && gy < a.H;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int gx = gx0 + k;
+          const bool ok = yok && gx >= 0 && gx < a.W;
+          m.off[i * 4 + k] = ok ? (unsigned)(((gy * a.W + gx) * Cin + 4 * pq) * 4) : 0x80000000u;
+        }
+      }
+    };
+    auto issue = [&](floatx4 (&d)[16], const Aim& m, int chunk) {
+#pragma unroll
+      for (int p = 0; p < 16; ++p)
+        d[p] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(m.rsrc, m.off[p], chunk * (CK * 4), 0));
+    };
+    // B^T d B in fp32, then the bf16 planes: hi = bf16(v), mid = bf16(v - hi) (, lo = bf16(v - hi - mid))
+    auto split_store = [&](floatx4 v, int pos) {
+      unsigned char* dst = vmine + pos * POSB;
+      const unsigned h0 = cvt_pk_bf16(v[0], v[1]), h1 = cvt_pk_bf16(v[2], v[3]);
+      *(uintx2*)dst = uintx2{h0, h1};
+      float r0 = v[0] - bf16_lo(h0), r1 = v[1] - bf16_hi(h0), r2 = v[2] - bf16_lo(h1), r3 = v[3] - bf16_hi(h1);
+      const unsigned m0 = cvt_pk_bf16(r0, r1), m1 = cvt_pk_bf16(r2, r3);
+      *(uintx2*)(dst + PLANEB) = uintx2{m0, m1};
+      if (P == 3) {
+        r0 -= bf16_lo(m0); r1 -= bf16_hi(m0); r2 -= bf16_lo(m1); r3 -= bf16_hi(m1);
+        *(uintx2*)(dst + 2 * PLANEB) = uintx2{cvt_pk_bf16(r0, r1), cvt_pk_bf16(r2, r3)};
+      }
+    };
+    auto commit = [&](floatx4 (&d)[16]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const floatx4 d0 = d[i * 4 + 0], d1 = d[i * 4 + 1], d2 = d[i * 4 + 2], d3 = d[i * 4 + 3];
+        d[i * 4 + 0] = sub4(d0, d2);
+        d[i * 4 + 1] = d1 + d2;
+        d[i * 4 + 2] = sub4(d2, d1);
+        d[i * 4 + 3] = sub4(d1, d3);
+      }
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) {
+        const floatx4 r0 = d[0 * 4 + nu], r1 = d[1 * 4 + nu], r2 = d[2 * 4 + nu], r3 = d[3 * 4 + nu];
+        split_store(sub4(r0, r2), 0 * 4 + nu);
+        split_store(r1 + r2, 1 * 4 + nu);
+        split_store(sub4(r2, r1), 2 * 4 + nu);
+        split_store(sub4(r1, r3), 3 * 4 + nu);
+      }
+    };
+    struct OutAim {
+      unsigned po[4];
+      __amdgpu_buffer_rsrc_t rs;
+    };
+    auto next_ticket = [&]() { return (int)(atomicAdd(a.ticket, 1ULL) + gridDim.x); };
+    auto aim_out = [&](OutAim& o, const Tile& t) {
+      const int phase = t.item & (a.nphase - 1);
+      const int ppy = phase >> 1, ppx = phase & 1;
+      const int OH = a.nphase == 4 ? 2 * a.H : a.H, OW = a.nphase == 4 ? 2 * a.W : a.W;
+      o.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)t.n * OH * OW * a.Cout), 0,
+                                               OH * OW * a.Cout * 4, 0x00020000);
+#pragma unroll
+      for (int ij = 0; ij < 4; ++ij) {
+        const int oy = t.ty * 8 + 2 * oty + (ij >> 1);
+        const int ox = t.tx * 16 + 2 * otx + (ij & 1);
+        const unsigned po =
+            (unsigned)(a.nphase == 4 ? ((2 * oy + ppy) * OW + (2 * ox + ppx)) * a.Cout
+                       : a.s2d       ? ((oy >> 1) * (a.W >> 1) + (ox >> 1)) * (4 * a.Cout) + ((oy & 1) * 2 + (ox & 1)) * a.Cout
+                                     : (oy * a.W + ox) * a.Cout) * 4u + 16u * oq;
+        o.po[ij] = oy < a.H && ox < a.W ? po : 0x80000000u;
+      }
+    };
+    auto store_outputs = [&](const OutAim& o) {
+      const float* src = yreg + yread;
+      const int ngroups = (a.Cout + 31) >> 5;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (g >= ngroups) break;
+        if (g == ngroups - 1 && g * 32 + 4 * oq >= a.Cout) continue;
+#pragma unroll
+        for (int ij = 0; ij < 4; ++ij) {
+          const floatx4 v = *(const floatx4*)(src + (ij * 4 + g) * 32 * WP);
+          if (a.nt_out)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), o.rs, o.po[ij], g * 128, 2);
+          else
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), o.rs, o.po[ij], g * 128, 0);
+        }
+      }
+    };
+
+    if (ht == 0) {
+      post(0, (int)blockIdx.x);
+      post(1, next_ticket());
+    }
+    __syncthreads();  // P0
+    Tile cur = read_slot(0);
+    // Each group keeps one patch in flight: (tile of the aim, chunk).  Group g's targets are the
+    // chunks of parity g; target k of a tile is committed during MFMA phase k-1 (phase n-1 of the
+    // previous tile for k = 0) and its loads are issued right behind the barrier two phases before.
+    Aim m;
+    floatx4 d[16];
+    int ticket_pre = a.ntiles;
+    aim(m, cur);
+    issue(d, m, grp);            // group 0: (cur, 0); group 1: (cur, 1)
+    if (grp == 0) {
+      commit(d);                 // V[0] = (cur, 0)
+      issue(d, m, 2);            // next target of group 0
+      if (ht == 0 && read_slot(1).item < a.ntiles) ticket_pre = next_ticket();
+    }
+    __syncthreads();  // P
+    int s_nxt = 1, s_wr = 2;
+    OutAim oa;
+    oa.rs = m.rsrc;
+#pragma unroll
+    for (int ij = 0; ij < 4; ++ij) oa.po[ij] = 0x80000000u;
+    bool have_y = false;
+    while (cur.item < a.ntiles) {
+      const Tile nxt = read_slot(s_nxt);
+      const bool more = nxt.item < a.ntiles;
+      for (int c = 0; c < nchunks; ++c) {
+        // phase c: the MFMA waves consume V[c & 1]
+        if (c == 0) {
+          if (have_y) store_outputs(oa);   // outputs of the previous tile (Y is rewritten at this tile's fold)
+          if (ht == 0 && more) post(s_wr, ticket_pre);
+        }
+        const bool mine = ((c + 1) & 1) == grp;
+        const int tgt = c + 1;             // tile-local target chunk; nchunks = (nxt, 0)
+        const bool tgt_valid = tgt < nchunks || more;
+        if (mine && tgt_valid) commit(d);
+        __syncthreads();  // B_c
+        if (mine) {
+          const int nt2 = c + 3;           // my next target
+          if (nt2 < nchunks) {
+            issue(d, m, nt2);
+          } else if (more) {
+            if (nt2 - nchunks < 2) aim(m, nxt);   // first target on the next tile
+            issue(d, m, nt2 - nchunks);
+          }
+        }
+      }
+      if (ht == 0 && more && read_slot(s_wr).item < a.ntiles) ticket_pre = next_ticket();
+      aim_out(oa, cur);
+      __syncthreads();  // E1
+      __syncthreads();  // E2
+      have_y = true;
+      cur = nxt;
+      const int s_old = s_nxt;
+      s_nxt = s_wr;
+      s_wr = s_old == 0 ? 2 : s_old - 1;
+    }
+    if (have_y) store_outputs(oa);
+    if (ht == 0) {
+      const unsigned long long done = atomicAdd(a.ticket + 1, 1ULL);
+      if (done == (unsigned long long)gridDim.x - 1) {
+        a.ticket[0] = 0ULL;
+        a.ticket[1] = 0ULL;
+      }
+    }
+    return;
+  }
+
+  // ===================================== MFMA waves ==============================================
+  const int h = lane >> 5, l31 = lane & 31;
+  const int nt = wave & 3, ph = wave >> 2;
+  const bool nvalid = nt * 32 < a.CoutP;
+  constexpr bool ZSKIP = MODE != 0;
+  constexpr int PDIR = MODE == 2 ? -1 : 1;
+  // U stream: [pos][chunk][plane][CoutP][16 bf16]; a fragment = 64 lanes x 16 bytes
+  const unsigned plane_b = (unsigned)a.CoutP * 32u;
+  const unsigned chunk_b = plane_b * (unsigned)P;
+  const unsigned pos_b = chunk_b * (unsigned)nchunks;
+  const unsigned ulane = (unsigned)((((nvalid ? nt : 0) * 32 + l31) * 2 + h) * 16);
+  auto pos_of = [](int pi) { return PDIR > 0 ? pi : 7 - pi; };
+  // V reads: row l31 of position ph*8+p, k-block h (swizzled)
+  const int aread = (ph * 8) * POSB + l31 * ROWB + ((h ^ ((l31 >> 3) & 1)) << 4);
+  float pbias = 0.f, pbeta = 1.f, pgamma = 0.f;
+  {
+    const int col = nt * 32 + l31;
+    if (col < a.Cout) {
+      pbias = a.bias[col];
+      if (a.act == DSIC_ACT_GDN || a.act == DSIC_ACT_IGDN) {
+        pbeta = a.beta[col];
+        pgamma = a.gamma[col];
+      }
+    }
+  }
+  floatx16 acc[8];
+  bf16x8 Bq[RING][P];
+  __syncthreads();  // P0
+  __syncthreads();  // P
+  Tile cur = read_slot(0);
+  const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)a.u, 0, (int)(16u * pos_b * (unsigned)a.nphase), 0x00020000);
+  // fetch stream position: (tile's phase, chunk, position index pi) -> scalar byte offset
+  unsigned soff_phase = (unsigned)(cur.item & (a.nphase - 1)) * (unsigned)a.u_phase_bytes;
+  auto soff_of = [&](unsigned phase_off, int chunk, int pi) {
+    return phase_off + (unsigned)(ph * 8 + pos_of(pi)) * pos_b + (unsigned)chunk * chunk_b;
+  };
+  auto fetch = [&](bf16x8 (&dst)[P], unsigned so) {
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+      dst[q] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(urs, ulane, so + (unsigned)q * plane_b, 0));
+  };
+#pragma unroll
+  for (int f = 0; f < RING; ++f) fetch(Bq[f], soff_of(soff_phase, 0, f));
+  int s_nxt = 1;
+  while (cur.item < a.ntiles) {
+    const Tile nxt = read_slot(s_nxt);
+    const unsigned soff_phase_nxt =
+        (unsigned)((nxt.item < a.ntiles ? nxt.item : cur.item) & (a.nphase - 1)) * (unsigned)a.u_phase_bytes;
+    auto chunk_body = [&](auto first_tag, int chunk) {
+      constexpr bool FIRST = decltype(first_tag)::value;
+      const bool last = chunk + 1 == nchunks;
+      unsigned zero_xi = 4, zero_nu = 4;
+      if (MODE == 1) {
+        const int blk = chunk / (nchunks >> 2);
+        if (blk >> 1) zero_xi = 3;
+        if (blk & 1) zero_nu = 3;
+      } else if (MODE == 2) {
+        const int phase = cur.item & 3;
+        if (phase >> 1) zero_xi = 0;
+        if (phase & 1) zero_nu = 0;
+      }
+      auto is_zero = [&](int pi) {
+        const int p = pos_of(pi);
+        const unsigned xi = (unsigned)(ph * 2 + (p >> 2)), nu = (unsigned)(p & 3);
+        return xi == zero_xi || nu == zero_nu;
+      };
+      const unsigned char* vb = lds_raw + (chunk & 1) * VBUFB + aread;
+      // one set of V fragments: the reads of step pi+1 are issued right behind the MFMAs of step pi
+      // (they land long after those MFMAs have read their sources); the second MFMA wave of the
+      // SIMD covers the LDS latency
+      bf16x8 Aq[P];
+#pragma unroll
+      for (int q = 0; q < P; ++q) Aq[q] = *(const bf16x8*)(vb + pos_of(0) * POSB + q * PLANEB);
+#pragma unroll
+      for (int pi = 0; pi < 8; ++pi) {
+        const int p0 = pos_of(pi);
+        const bool live = !ZSKIP || !is_zero(pi);  // wave-uniform
+        if (live) {
+          const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          floatx16 c = FIRST ? zero : acc[p0];
+          if (P == 3) {  // small terms first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[0], Bq[pi % RING][P - 1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[P - 1], Bq[pi % RING][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[1], Bq[pi % RING][1], c, 0, 0, 0);
+          }
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[0], Bq[pi % RING][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[1], Bq[pi % RING][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[0], Bq[pi % RING][0], c, 0, 0, 0);
+          acc[p0] = c;
+        } else if (FIRST) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[p0][e] = 0.f;
+        }
+        if (pi + 1 < 8) {
+#pragma unroll
+          for (int q = 0; q < P; ++q) Aq[q] = *(const bf16x8*)(vb + pos_of(pi + 1) * POSB + q * PLANEB);
+        }
+        {
+          // refill this ring slot with the fragments of step pi + RING (next chunk / next tile past 7)
+          const int f = pi + RING;
+          const unsigned so = f < 8 ? soff_of(soff_phase, chunk, f)
+                                    : (last ? soff_of(soff_phase_nxt, 0, f - 8) : soff_of(soff_phase, chunk + 1, f - 8));
+          fetch(Bq[pi % RING], so);
+        }
+      }
+      __syncthreads();  // B_chunk
+    };
+    chunk_body(std::true_type{}, 0);
+    for (int chunk = 1; chunk < nchunks; ++chunk) chunk_body(std::false_type{}, chunk);
+    soff_phase = soff_phase_nxt;
+
+    // ---- inverse transform (as conv_wino.hip) -----------------------------------------------
+    {
+      float* yown = yreg + ((4 * (2 * ph) + nt) * 32 + 4 * h) * WP + l31;
+      float* yoth = yreg + ((4 * (2 * (ph ^ 1)) + nt) * 32 + 4 * h) * WP + l31;
+      floatx16 send[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const floatx16 na = j == 0 ? (acc[0] + acc[1]) + acc[2] : sub16(sub16(acc[1], acc[2]), acc[3]);
+        const floatx16 nb = j == 0 ? (acc[4] + acc[5]) + acc[6] : sub16(sub16(acc[5], acc[6]), acc[7]);
+        const floatx16 own = ph == 0 ? na + nb : -(na + nb);
+        send[j] = ph == 0 ? nb : na;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) yown[(4 * j * 32 + (e & 3) + 8 * (e >> 2)) * WP] = own[e];
+      }
+      __syncthreads();  // E1
+      auto finish_rows = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          floatx16 got;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) got[e] = yoth[(4 * j * 32 + (e & 3) + 8 * (e >> 2)) * WP];
+#pragma unroll
+          for (int e = 0; e < 16; e += 2) {
+            floatx2 v = {got[e], got[e + 1]};
+            v = v + floatx2{send[j][e], send[j][e + 1]};
+            v = v + floatx2{pbias, pbias};
+            if (ACT == DSIC_ACT_GDN || ACT == DSIC_ACT_IGDN) {
+              v = gdn_pair<ACT == DSIC_ACT_IGDN>(v, floatx2{pbeta, pbeta}, floatx2{pgamma, pgamma});
+            } else if (ACT == DSIC_ACT_RELU) {
+              v[0] = v[0] > 0.f ? v[0] : 0.f;
+              v[1] = v[1] > 0.f ? v[1] : 0.f;
+            }
+            yoth[(4 * j * 32 + (e & 3) + 8 * (e >> 2)) * WP] = v[0];
+            yoth[(4 * j * 32 + ((e + 1) & 3) + 8 * ((e + 1) >> 2)) * WP] = v[1];
+          }
+        }
+      };
+      if (a.act == DSIC_ACT_GDN)
+        finish_rows(std::integral_constant<int, DSIC_ACT_GDN>{});
+      else if (a.act == DSIC_ACT_IGDN)
+        finish_rows(std::integral_constant<int, DSIC_ACT_IGDN>{});
+      else if (a.act == DSIC_ACT_RELU)
+        finish_rows(std::integral_constant<int, DSIC_ACT_RELU>{});
+      else
+        finish_rows(std::integral_constant<int, DSIC_ACT_NONE>{});
+    }
+    __syncthreads();  // E2
+    cur = nxt;
+    s_nxt = s_nxt == 2 ? 0 : s_nxt + 1;
+  }
+}
+
+// fp32 transformed weights [16][Cin/8][CoutP][8] (dsic_pack_wino_*_weight, one block per phase) ->
+// bf16 planes [16][Cin/16][PLANES][CoutP][16]
+__global__ void split_u_kernel(const float* __restrict__ u32, unsigned short* __restrict__ dst, int Cin, int CoutP,
+                               int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one per (pos, chunk, n, k)
+  if (i >= total) return;
+  const int k = i & 15;
+  int64_t r = i >> 4;
+  const int n = r % CoutP;
+  r /= CoutP;
+  const int nchunks = Cin / CK;
+  const int chunk = r % nchunks;
+  const int pos = r / nchunks;
+  const int c = chunk * CK + k;
+  const float v = u32[(((size_t)pos * (Cin / 8) + (c >> 3)) * CoutP + n) * 8 + (c & 7)];
+  float rem = v;
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    const unsigned pk = cvt_pk_bf16(rem, 0.f);
+    dst[((((size_t)pos * nchunks + chunk) * P + q) * CoutP + n) * 16 + k] = (unsigned short)(pk & 0xFFFFu);
+    rem = rem - bf16_lo(pk);
+  }
+}
+
+}  // namespace wb
+}  // namespace dsic
+
+using namespace dsic;
+
+extern "C" int dsic_wino_bf16_planes(void) { return wb::P; }
+
+extern "C" int64_t dsic_wino_bf16_weight_bytes(int Cout, int Cin) {
+  return (int64_t)16 * (Cin / wb::CK) * wb::P * round_up(Cout, 32) * 16 * 2;
+}
+
+extern "C" int dsic_split_wino_weight_bf16(const float* u_f32, void* dst, int Cout, int Cin, int nphase,
+                                           void* stream) {
+  DSIC_REQUIRE(u_f32 && dst && Cout > 0 && Cin > 0 && Cin % 32 == 0 && (nphase == 1 || nphase == 4),
+               "split_wino_weight_bf16: bad argument");
+  const int CoutP = round_up(Cout, 32);
+  const int64_t total = (int64_t)16 * Cin * CoutP;
+  const int64_t fstride = (int64_t)16 * (Cin / 8) * CoutP * 8;
+  for (int ph = 0; ph < nphase; ++ph)
+    hipLaunchKernelGGL(wb::split_u_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       u_f32 + (size_t)ph * fstride,
+                       (unsigned short*)((unsigned char*)dst + (size_t)ph * dsic_wino_bf16_weight_bytes(Cout, Cin)), Cin,
+                       CoutP, total);
+  return check_launch("split_wino_weight_bf16");
+}
+
+static int wb_launch(wb::Args& a, hipStream_t st) {
+  const int B = a.B, H = a.H, W = a.W;
+  a.tiles_x = ceil_div(W, 16);
+  a.tiles_y = ceil_div(H, 8);
+  const int64_t nt = (int64_t)a.tiles_x * a.tiles_y * B * a.nphase;
+  DSIC_REQUIRE(nt < ((int64_t)1 << 31), "conv_wino_bf16: too many tiles");
+  DSIC_REQUIRE((int64_t)H * W * a.Cin * 4 < ((int64_t)1 << 31) &&
+                   (int64_t)H * W * a.Cout * 4 * (a.nphase == 4 ? 4 : 1) < ((int64_t)1 << 31),
+               "conv_wino_bf16: one image must stay below 2 GiB (32-bit offsets inside an image)");
+  DSIC_REQUIRE(a.u_phase_bytes * a.nphase < ((int64_t)1 << 31), "conv_wino_bf16: transformed weights must stay below 2 GiB");
+  a.ntiles = (int)nt;
+  a.nt_out = (int64_t)B * H * W * a.Cout * 4 * (a.nphase == 4 ? 4 : 1) > (300ll << 20);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  static bool attr_set[64] = {};
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (!attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute((const void*)wb::conv_wino_bf16_kernel<0>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, wb::LDS_TOTAL);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)wb::conv_wino_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              wb::LDS_TOTAL);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)wb::conv_wino_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              wb::LDS_TOTAL);
+    if (e != hipSuccess) {
+      set_error("conv_wino_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return DSIC_EHIP;
+    }
+    attr_set[dev] = true;
+  }
+  static int max_grid = 0;
+  if (max_grid == 0) {
+    const char* g = getenv("DSIC_WINO_GRID");
+    max_grid = g ? atoi(g) : 256;
+    if (max_grid < 1 || max_grid > 1024) max_grid = 256;
+  }
+  const int grid = a.ntiles < max_grid ? a.ntiles : max_grid;
+  if (a.s2d_in)
+    hipLaunchKernelGGL(wb::conv_wino_bf16_kernel<1>, dim3(grid), dim3(wb::THREADS), wb::LDS_TOTAL, st, a);
+  else if (a.nphase == 4)
+    hipLaunchKernelGGL(wb::conv_wino_bf16_kernel<2>, dim3(grid), dim3(wb::THREADS), wb::LDS_TOTAL, st, a);
+  else
+    hipLaunchKernelGGL(wb::conv_wino_bf16_kernel<0>, dim3(grid), dim3(wb::THREADS), wb::LDS_TOTAL, st, a);
+  return check_launch("conv_wino_bf16");
+}
+
+extern "C" int dsic_conv3x3_wino_bf16_nhwc(const float* in, const void* u_planes, const float* bias,
+                                           const float* beta, const float* gamma, float* out, int B, int H,
+                                           int W, int Cin, int Cout, int act, int s2d_out, int s2d_in,
+                                           void* ticket, void* stream) {
+  DSIC_REQUIRE(in && u_planes && bias && out && ticket, "conv3x3_wino_bf16: null pointer");
+  DSIC_REQUIRE(B > 0 && H > 0 && W > 0, "conv3x3_wino_bf16: empty tensor");
+  DSIC_REQUIRE(Cin >= 64 && Cin % 32 == 0, "conv3x3_wino_bf16: Cin=%d must be a multiple of 32, >= 64", Cin);
+  DSIC_REQUIRE(Cout > 0 && Cout % 4 == 0 && Cout <= 128, "conv3x3_wino_bf16: Cout=%d must be a multiple of 4, <= 128", Cout);
+  DSIC_REQUIRE(act >= 0 && act <= 3, "conv3x3_wino_bf16: act=%d", act);
+  DSIC_REQUIRE(!(act == DSIC_ACT_GDN || act == DSIC_ACT_IGDN) || (beta && gamma), "conv3x3_wino_bf16: GDN needs beta and gamma");
+  DSIC_REQUIRE(!s2d_out || (H % 2 == 0 && W % 2 == 0), "conv3x3_wino_bf16: space-to-depth output needs even H and W");
+  DSIC_REQUIRE(!s2d_in || Cin % 128 == 0, "conv3x3_wino_bf16: space-to-depth input needs Cin = 4*Cs with Cs %% 32 == 0");
+  wb::Args a{};
+  a.in = in; a.u = u_planes; a.bias = bias; a.beta = beta; a.gamma = gamma; a.out = out;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.CoutP = round_up(Cout, 32); a.act = act;
+  a.s2d = s2d_out; a.s2d_in = s2d_in ? 1 : 0;
+  a.ticket = (unsigned long long*)ticket;
+  a.nphase = 1; a.u_phase_bytes = dsic_wino_bf16_weight_bytes(Cout, Cin);
+  return wb_launch(a, (hipStream_t)stream);
+}
+
+extern "C" int dsic_conv_transpose2d_wino_bf16_nhwc(const float* in, const void* u_planes4, const float* bias,
+                                                    const float* beta, const float* gamma, float* out, int B,
+                                                    int H, int W, int Cin, int Cout, int act, void* ticket,
+                                                    void* stream) {
+  DSIC_REQUIRE(in && u_planes4 && bias && out && ticket, "convT_wino_bf16: null pointer");
+  DSIC_REQUIRE(B > 0 && H > 0 && W > 0, "convT_wino_bf16: empty tensor");
+  DSIC_REQUIRE(Cin >= 64 && Cin % 32 == 0, "convT_wino_bf16: Cin=%d must be a multiple of 32, >= 64", Cin);
+  DSIC_REQUIRE(Cout > 0 && Cout % 4 == 0 && Cout <= 128, "convT_wino_bf16: Cout=%d must be a multiple of 4, <= 128", Cout);
+  DSIC_REQUIRE(act >= 0 && act <= 3, "convT_wino_bf16: act=%d", act);
+  DSIC_REQUIRE(!(act == DSIC_ACT_GDN || act == DSIC_ACT_IGDN) || (beta && gamma), "convT_wino_bf16: IGDN needs beta and gamma");
+  wb::Args a{};
+  a.in = in; a.u = u_planes4; a.bias = bias; a.beta = beta; a.gamma = gamma; a.out = out;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.CoutP = round_up(Cout, 32); a.act = act;
+  a.ticket = (unsigned long long*)ticket;
+  a.s2d = 0; a.s2d_in = 0; a.nphase = 4; a.u_phase_bytes = dsic_wino_bf16_weight_bytes(Cout, Cin);
+  return wb_launch(a, (hipStream_t)stream);
+}

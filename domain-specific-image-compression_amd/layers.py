@@ -20,6 +20,9 @@ from . import ops
 
 # DSIC_WINOGRAD=0 forces the direct implicit-GEMM kernel for every layer (A/B runs)
 USE_WINOGRAD = os.environ.get("DSIC_WINOGRAD", "1") != "0"
+# Winograd position GEMMs on the bf16 MFMA path with operands split into bf16 planes (fp32-class
+# results, csrc/conv_wino_bf16.hip); DSIC_WINO_BF16=0 selects the fp32-input MFMA kernel.
+WINO_BF16 = os.environ.get("DSIC_WINO_BF16", "1") != "0"
 
 
 class _GammaConv(nn.Module):
@@ -120,6 +123,9 @@ class Conv2d(_ConvBase):
         if getattr(self, "_wino", None) is None or self._wino_key != key:
             self._wino = (ops.pack_wino_s2_weight(self.weight) if self.kernel_size == 5
                           else ops.pack_wino_weight(self.weight))
+            cin = self.in_channels * (4 if self.kernel_size == 5 else 1)
+            if WINO_BF16 and cin >= 64:
+                self._wino = ops.split_wino_weight_bf16(self._wino, self.out_channels, cin, 1)
             self._wino_key = key
         return self._wino
 
@@ -181,7 +187,10 @@ class ConvTranspose2d(_ConvBase):
         if self.to_image:
             return ops.pack_convT_image_weight(self.weight)
         if self.use_winograd:
-            return ops.pack_wino_convT_weight(self.weight)
+            u = ops.pack_wino_convT_weight(self.weight)
+            if WINO_BF16 and self.in_channels >= 64:
+                u = ops.split_wino_weight_bf16(u, self.out_channels, self.in_channels, 4)
+            return u
         return ops.pack_convT_weight(self.weight)
 
     def run_nhwc(self, x, act=ops.ACT_NONE, gdn=None):

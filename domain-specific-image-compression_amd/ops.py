@@ -194,14 +194,37 @@ def pack_wino_convT_weight(w: torch.Tensor) -> torch.Tensor:
     return dst
 
 
+def split_wino_weight_bf16(u_f32: torch.Tensor, Cout: int, Cin: int, nphase: int = 1) -> torch.Tensor:
+    """fp32 transformed weights (pack_wino_*_weight) -> bf16 planes for the *_wino_bf16 kernels (uint8 tensor)."""
+    L = _lib.load()
+    dst = torch.empty(nphase * L.dsic_wino_bf16_weight_bytes(Cout, Cin), dtype=torch.uint8, device=u_f32.device)
+    _lib.check(L.dsic_split_wino_weight_bf16(_p(u_f32), _p(dst), Cout, Cin, nphase, _stream()), "split_wino_weight_bf16")
+    return dst
+
+
+def wino_bf16_planes() -> int:
+    return int(_lib.load().dsic_wino_bf16_planes())
+
+
 def conv_transpose2d_wino_nhwc(x, u_packed4, bias, Cout, act=ACT_NONE, beta=None, gamma=None, out=None):
-    """ConvTranspose2d(Cin,Cout,5,2,2,1) + fused activation: four Winograd 3x3 phase convs."""
+    """ConvTranspose2d(Cin,Cout,5,2,2,1) + fused activation: four Winograd 3x3 phase convs.
+    u_packed4: fp32 transformed weights (fp32 MFMA kernel) or the uint8 bf16 planes of
+    split_wino_weight_bf16 (split-bf16 kernel)."""
     x = _f32c(x, "conv_transpose2d_wino_nhwc")
     B, H, W, Cin = x.shape
     if out is None:
         out = torch.empty((B, 2 * H, 2 * W, Cout), dtype=torch.float32, device=x.device)
     L = _lib.load()
     wino_tiles = 4 * B * (-(-H // 8)) * (-(-W // 16)) * 32
+    if u_packed4.dtype == torch.uint8:
+        nprod = 3 if wino_bf16_planes() == 2 else 6
+        _timed("conv_wino_bf16_kernel<2>", 2.0 * B * H * W * Cout * Cin * 25,
+               lambda: _lib.check(L.dsic_conv_transpose2d_wino_bf16_nhwc(_p(x), _p(u_packed4), _p(bias), _p(beta),
+                                                                         _p(gamma), _p(out), B, H, W, Cin, Cout, act,
+                                                                         _p(_ticket(x.device)), _stream()),
+                                  "conv_transpose2d_wino_bf16_nhwc"),
+               exec_flops=2.0 * nprod * wino_tiles * 12.25 * Cin * round_up(Cout, 32))
+        return out
     _timed("conv_wino_kernel<2>", 2.0 * B * H * W * Cout * Cin * 25,
            lambda: _lib.check(L.dsic_conv_transpose2d_wino_nhwc(_p(x), _p(u_packed4), _p(bias), _p(beta), _p(gamma),
                                                                 _p(out), B, H, W, Cin, Cout, act, _p(_ticket(x.device)),
@@ -235,6 +258,16 @@ def conv3x3_wino_nhwc(x, u_packed, bias, Cout, act=ACT_NONE, beta=None, gamma=No
         out = torch.empty(shape, dtype=torch.float32, device=x.device)
     L = _lib.load()
     wino_tiles = B * (-(-H // 8)) * (-(-W // 16)) * 32          # 2x2-output tiles incl. border padding
+    if u_packed.dtype == torch.uint8:                            # bf16 planes: split-bf16 kernel
+        nprod = 3 if wino_bf16_planes() == 2 else 6
+        _timed("conv_wino_bf16_kernel<1>" if s2d_in else "conv_wino_bf16_kernel<0>",
+               algo_flops if algo_flops is not None else 2.0 * B * H * W * Cout * Cin * 9,
+               lambda: _lib.check(L.dsic_conv3x3_wino_bf16_nhwc(_p(x), _p(u_packed), _p(bias), _p(beta), _p(gamma),
+                                                                _p(out), B, H, W, Cin, Cout, act, int(bool(s2d_out)),
+                                                                int(bool(s2d_in)), _p(_ticket(x.device)), _stream()),
+                                  "conv3x3_wino_bf16_nhwc"),
+               exec_flops=2.0 * nprod * wino_tiles * (12.25 if s2d_in else 16) * Cin * round_up(Cout, 32))
+        return out
     _timed("conv_wino_kernel<1>" if s2d_in else "conv_wino_kernel<0>",
            algo_flops if algo_flops is not None else 2.0 * B * H * W * Cout * Cin * 9,
            lambda: _lib.check(L.dsic_conv3x3_wino_nhwc(_p(x), _p(u_packed), _p(bias), _p(beta), _p(gamma), _p(out),

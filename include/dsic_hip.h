@@ -136,6 +136,29 @@ int dsic_conv_transpose2d_wino_nhwc(const float* in, const float* u_packed4,
                                     int H, int W, int Cin, int Cout, int act,
                                     void* ticket, void* stream);
 
+/* Winograd layers on the bf16 MFMA path with fp32-class results (csrc/conv_wino_bf16.hip): the
+ * fp32 operands are split into bf16 planes (x = hi + mid [+ lo]) and the cross products are
+ * accumulated in fp32.  dsic_wino_bf16_planes(): planes the library was built with (2: products
+ * hh, hm, mh; 3: + mm, hl, lh).  u_f32: transformed weights as written by dsic_pack_wino_weight /
+ * dsic_pack_wino_s2_weight (nphase 1) or dsic_pack_wino_convT_weight (nphase 4); dst:
+ * nphase * dsic_wino_bf16_weight_bytes(Cout, Cin) bytes, [phase][16][Cin/16][planes][CoutP][16] bf16.
+ * The two conv entry points mirror dsic_conv3x3_wino_nhwc / dsic_conv_transpose2d_wino_nhwc
+ * (same layers of code/modelv2/layers.py:54-72, 83-97, 108-124; Cin a multiple of 32, >= 64). */
+int dsic_wino_bf16_planes(void);
+int64_t dsic_wino_bf16_weight_bytes(int Cout, int Cin);
+int dsic_split_wino_weight_bf16(const float* u_f32, void* dst, int Cout, int Cin,
+                                int nphase, void* stream);
+int dsic_conv3x3_wino_bf16_nhwc(const float* in, const void* u_planes,
+                                const float* bias, const float* beta,
+                                const float* gamma, float* out, int B, int H, int W,
+                                int Cin, int Cout, int act, int s2d_out, int s2d_in,
+                                void* ticket, void* stream);
+int dsic_conv_transpose2d_wino_bf16_nhwc(const float* in, const void* u_planes4,
+                                         const float* bias, const float* beta,
+                                         const float* gamma, float* out, int B,
+                                         int H, int W, int Cin, int Cout, int act,
+                                         void* ticket, void* stream);
+
 /* First analysis layer conv(Cimg,Cout,3,1) + optional GDN/ReLU (layers.py:51)
  * read straight from the NCHW image [B,Cimg,H,W] (Cimg 3 or 4) with K = 9*Cimg;
  * w_oihw is the reference weight [Cout,Cimg,3,3] unpacked; out NHWC [B,H,W,Cout],
