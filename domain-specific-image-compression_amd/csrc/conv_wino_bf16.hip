@@ -20,9 +20,10 @@
 //     the two V planes (2 ds_read_b128), takes the two U planes from its register ring
 //     (transformed weights, bf16, [pos][chunk][plane][CoutP][16], streamed from L2) and issues
 //     3 MFMAs.
-//   * the helpers form two groups (waves 8,9 / 10,11): group g loads, transforms (B^T d B in fp32),
-//     splits and stores the chunks of parity g into V buffer g while the MFMA waves consume the
-//     other buffer, and is idle (copying finished outputs to HBM) during the next chunk.
+//   * the four helper waves (one per SIMD) share every chunk: thread = (Winograd tile, channel quad,
+//     half of the positions); it loads three rows of the 4x4 patch, applies B^T d B in fp32, splits
+//     into the bf16 planes and stores them into the V buffer the MFMA waves are not reading.  Two
+//     patches per thread are in flight, so a load has two MFMA phases to arrive.
 // Tile hand-out, the fold through LDS and the fused epilogue are those of conv_wino.hip.
 #include <stdlib.h>
 
@@ -32,6 +33,12 @@
 
 #ifndef WB_PLANES
 #define WB_PLANES 2
+#endif
+#ifndef WB_STAMP
+#define WB_STAMP 0   // diagnostic: cycle stamps of MFMA wave 0 and helper wave 8 for one tile (tools/wb_stamps.py)
+#endif
+#ifndef WB_STAMP_TILE
+#define WB_STAMP_TILE 8
 #endif
 
 namespace dsic {
@@ -72,11 +79,24 @@ constexpr int WP = 36;                          // floats per (plane, tile) row 
 constexpr int YOFF = 2 * VBUFB;                 // byte offset of the output region
 constexpr int YBYTES = 16 * 32 * WP * 4;        // 73728
 constexpr int SLOTOFF = YOFF + YBYTES;
-constexpr int LDS_TOTAL = SLOTOFF + 64;
+constexpr int LDS_TOTAL = SLOTOFF + 64 + (WB_STAMP ? 1024 : 0);
 constexpr int THREADS = 768;
 constexpr int RING = 2;                         // position-steps of U fragments in flight per MFMA wave
 
 static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
+
+#if WB_STAMP
+__device__ long long wb_stamps[256 * 128];
+#define WSTAMP(w, i)                                                                               \
+  do {                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    if (lane == 0 && wave == (w) && tile_count == WB_STAMP_TILE && (i) < 64)                       \
+      ((long long*)(lds_raw + SLOTOFF + 64))[((w) == 0 ? 0 : 64) + (i)] = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+  } while (0)
+#else
+#define WSTAMP(w, i)
+#endif
 
 __device__ __forceinline__ floatx2 pk_sub(floatx2 a, floatx2 b) {
   floatx2 r;
@@ -130,16 +150,22 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
 
   if (wave >= 8) {
     // =================================== helper waves ===========================================
+    // Every chunk is produced by all four helper waves (one per SIMD, so the VALU work is spread
+    // evenly beside the MFMA waves): thread = (Winograd tile pt, channel quad pq of the 16-channel
+    // chunk, row half hx).  Half hx owns the positions xi in {2hx, 2hx+1}: they need only three of
+    // the four patch rows (xi 0: r0-r2, 1: r1+r2 | 2: r2-r1, 3: r1-r3), i.e. 12 float4 loads.
+    // Two patches are in flight per thread (sets S0, S1): target chunk k lives in set k&1, is
+    // committed to V[k&1] during MFMA phase k-1, and the loads of target k+2 are issued into the
+    // same set right behind the barrier that ends that phase - two full phases before their use.
     const int ht = tid - 512;
-    const int grp = __builtin_amdgcn_readfirstlane(ht >> 7);  // chunk parity this thread produces
+    const int hx = __builtin_amdgcn_readfirstlane(ht >> 7);
     const int Cin = a.Cin;
-    // input side: thread = (Winograd tile pt, channel quad pq of the 16-channel chunk)
     const int t7 = ht & 127;
     const int pt = t7 >> 2, pq = t7 & 3;
     const int ptx = pt & 7, pty = pt >> 3;
     // LDS byte offset of this thread's 8 bytes inside a (plane, pos) block
     const int vwrite = pt * ROWB + ((((pq >> 1) ^ ((pt >> 3) & 1))) << 4) + ((pq & 1) << 3);
-    unsigned char* const vmine = lds_raw + grp * VBUFB + vwrite;
+    unsigned char* const vmine = lds_raw + vwrite + (2 * hx) * 4 * POSB;  // + buffer + plane + local pos
     // output side: thread = (Winograd tile ot, channel quad oq of a 32-channel group), all 256 helpers
     const int ot = ht >> 3, oq = ht & 7;
     const int otx = ot & 7, oty = ot >> 3;
@@ -150,16 +176,22 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
       const intx4 v = {item, tile - row * a.tiles_x, row % a.tiles_y, row / a.tiles_y};
       *(intx4*)(slots + 4 * s) = v;
     };
+    struct Patch {
+      floatx4 d[12];      // pixel rows hx, hx+1, hx+2 of the 4x4 patch, 4 columns each
+    };
+    // One aim serves both sets: every load issued before phase n-3 of a tile targets that tile,
+    // every load from phase n-3 on targets the next one (targets n, n+1, n+2 = its chunks 0, 1, 2).
     struct Aim {
-      unsigned off[16];
+      unsigned off[12];   // byte offsets of the 12 pixels inside the image (out of range = reads 0)
       __amdgpu_buffer_rsrc_t rsrc;
     };
+    Aim am;
     auto aim = [&](Aim& m, const Tile& t) {
-      const int gy0 = t.ty * 8 + 2 * pty - 1, gx0 = t.tx * 16 + 2 * ptx - 1;
+      const int gy0 = t.ty * 8 + 2 * pty - 1 + hx, gx0 = t.tx * 16 + 2 * ptx - 1;
       m.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)t.n * a.H * a.W * Cin), 0,
                                                  a.H * a.W * Cin * 4, 0x00020000);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 3; ++i) {
         const int gy = gy0 + i;
         const bool yok = gy >= 0 && gy < a.H;
 #pragma unroll
@@ -170,14 +202,13 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
         }
       }
     };
-    auto issue = [&](floatx4 (&d)[16], const Aim& m, int chunk) {
+    auto issue = [&](Patch& m, int chunk) {
 #pragma unroll
-      for (int p = 0; p < 16; ++p)
-        d[p] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(m.rsrc, m.off[p], chunk * (CK * 4), 0));
+      for (int p = 0; p < 12; ++p)
+        m.d[p] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(am.rsrc, am.off[p], chunk * (CK * 4), 0));
     };
-    // B^T d B in fp32, then the bf16 planes: hi = bf16(v), mid = bf16(v - hi) (, lo = bf16(v - hi - mid))
-    auto split_store = [&](floatx4 v, int pos) {
-      unsigned char* dst = vmine + pos * POSB;
+    // fp32 value -> bf16 planes: hi = bf16(v), mid = bf16(v - hi) (, lo = bf16(v - hi - mid))
+    auto split_store = [&](floatx4 v, unsigned char* dst) {
       const unsigned h0 = cvt_pk_bf16(v[0], v[1]), h1 = cvt_pk_bf16(v[2], v[3]);
       *(uintx2*)dst = uintx2{h0, h1};
       float r0 = v[0] - bf16_lo(h0), r1 = v[1] - bf16_hi(h0), r2 = v[2] - bf16_lo(h1), r3 = v[3] - bf16_hi(h1);
@@ -188,23 +219,30 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
         *(uintx2*)(dst + 2 * PLANEB) = uintx2{cvt_pk_bf16(r0, r1), cvt_pk_bf16(r2, r3)};
       }
     };
-    auto commit = [&](floatx4 (&d)[16]) {
+    // B^T d B for this thread's two xi rows, into V buffer vb (0/1)
+    auto commit = [&](const Patch& m, int vb) {
+      unsigned char* dst = vmine + vb * VBUFB;
+      floatx4 xlo[4], xhi[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const floatx4 d0 = d[i * 4 + 0], d1 = d[i * 4 + 1], d2 = d[i * 4 + 2], d3 = d[i * 4 + 3];
-        d[i * 4 + 0] = sub4(d0, d2);
-        d[i * 4 + 1] = d1 + d2;
-        d[i * 4 + 2] = sub4(d2, d1);
-        d[i * 4 + 3] = sub4(d1, d3);
+      for (int k = 0; k < 4; ++k) {
+        const floatx4 ra = m.d[0 * 4 + k], rb = m.d[1 * 4 + k], rc = m.d[2 * 4 + k];
+        if (hx == 0) {   // wave-uniform
+          xlo[k] = ra - rc;   // xi 0: r0 - r2
+          xhi[k] = rb + rc;   // xi 1: r1 + r2
+        } else {
+          xlo[k] = rb - ra;   // xi 2: r2 - r1
+          xhi[k] = ra - rc;   // xi 3: r1 - r3
+        }
       }
-#pragma unroll
-      for (int nu = 0; nu < 4; ++nu) {
-        const floatx4 r0 = d[0 * 4 + nu], r1 = d[1 * 4 + nu], r2 = d[2 * 4 + nu], r3 = d[3 * 4 + nu];
-        split_store(sub4(r0, r2), 0 * 4 + nu);
-        split_store(r1 + r2, 1 * 4 + nu);
-        split_store(sub4(r2, r1), 2 * 4 + nu);
-        split_store(sub4(r1, r3), 3 * 4 + nu);
-      }
+      // columns: nu 0: x0-x2, 1: x1+x2, 2: x2-x1, 3: x1-x3
+      split_store(xlo[0] - xlo[2], dst + 0 * POSB);
+      split_store(xlo[1] + xlo[2], dst + 1 * POSB);
+      split_store(xlo[2] - xlo[1], dst + 2 * POSB);
+      split_store(xlo[1] - xlo[3], dst + 3 * POSB);
+      split_store(xhi[0] - xhi[2], dst + 4 * POSB);
+      split_store(xhi[1] + xhi[2], dst + 5 * POSB);
+      split_store(xhi[2] - xhi[1], dst + 6 * POSB);
+      split_store(xhi[1] - xhi[3], dst + 7 * POSB);
     };
     struct OutAim {
       unsigned po[4];
@@ -228,21 +266,22 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
         o.po[ij] = oy < a.H && ox < a.W ? po : 0x80000000u;
       }
     };
-    auto store_outputs = [&](const OutAim& o) {
+    // one 32-channel group of the finished outputs: 4 LDS reads + 4 buffer stores per thread.  The
+    // groups of a tile are copied out one per chunk pair of the NEXT tile: the vector-memory path
+    // issues a 1 KB store instruction in >= 16 cycles, and all 64 KB behind one barrier would hold
+    // the MFMA waves for thousands of cycles.
+    auto store_group = [&](const OutAim& o, int g) {
       const float* src = yreg + yread;
       const int ngroups = (a.Cout + 31) >> 5;
+      if (g >= ngroups) return;
+      if (g == ngroups - 1 && g * 32 + 4 * oq >= a.Cout) return;  // partial last group (Cout % 32 != 0)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        if (g >= ngroups) break;
-        if (g == ngroups - 1 && g * 32 + 4 * oq >= a.Cout) continue;
-#pragma unroll
-        for (int ij = 0; ij < 4; ++ij) {
-          const floatx4 v = *(const floatx4*)(src + (ij * 4 + g) * 32 * WP);
-          if (a.nt_out)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), o.rs, o.po[ij], g * 128, 2);
-          else
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), o.rs, o.po[ij], g * 128, 0);
-        }
+      for (int ij = 0; ij < 4; ++ij) {
+        const floatx4 v = *(const floatx4*)(src + (ij * 4 + g) * 32 * WP);
+        if (a.nt_out)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), o.rs, o.po[ij], g * 128, 2);
+        else
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), o.rs, o.po[ij], g * 128, 0);
       }
     };
 
@@ -252,49 +291,51 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
     }
     __syncthreads();  // P0
     Tile cur = read_slot(0);
-    // Each group keeps one patch in flight: (tile of the aim, chunk).  Group g's targets are the
-    // chunks of parity g; target k of a tile is committed during MFMA phase k-1 (phase n-1 of the
-    // previous tile for k = 0) and its loads are issued right behind the barrier two phases before.
-    Aim m;
-    floatx4 d[16];
+    Patch S0, S1;
     int ticket_pre = a.ntiles;
-    aim(m, cur);
-    issue(d, m, grp);            // group 0: (cur, 0); group 1: (cur, 1)
-    if (grp == 0) {
-      commit(d);                 // V[0] = (cur, 0)
-      issue(d, m, 2);            // next target of group 0
-      if (ht == 0 && read_slot(1).item < a.ntiles) ticket_pre = next_ticket();
-    }
+    aim(am, cur);
+    issue(S0, 0);
+    issue(S1, 1);
+    commit(S0, 0);               // V[0] = (cur, 0)
+    issue(S0, 2);
+    if (ht == 0 && read_slot(1).item < a.ntiles) ticket_pre = next_ticket();
     __syncthreads();  // P
     int s_nxt = 1, s_wr = 2;
     OutAim oa;
-    oa.rs = m.rsrc;
+    oa.rs = am.rsrc;
 #pragma unroll
     for (int ij = 0; ij < 4; ++ij) oa.po[ij] = 0x80000000u;
     bool have_y = false;
+    int tile_count = 0;
+    (void)tile_count;
     while (cur.item < a.ntiles) {
       const Tile nxt = read_slot(s_nxt);
       const bool more = nxt.item < a.ntiles;
-      for (int c = 0; c < nchunks; ++c) {
-        // phase c: the MFMA waves consume V[c & 1]
-        if (c == 0) {
-          if (have_y) store_outputs(oa);   // outputs of the previous tile (Y is rewritten at this tile's fold)
-          if (ht == 0 && more) post(s_wr, ticket_pre);
-        }
-        const bool mine = ((c + 1) & 1) == grp;
-        const int tgt = c + 1;             // tile-local target chunk; nchunks = (nxt, 0)
-        const bool tgt_valid = tgt < nchunks || more;
-        if (mine && tgt_valid) commit(d);
+      tile_count++;
+      // one phase: commit target c+1 (set S, buffer (c+1)&1), barrier, issue target c+3 into S
+      auto phase = [&](Patch& S, int c) {
+        const int tgt = c + 1;
+        WSTAMP(8, 3 * c);
+        if (tgt < nchunks || more) commit(S, tgt & 1);
+        WSTAMP(8, 3 * c + 1);
         __syncthreads();  // B_c
-        if (mine) {
-          const int nt2 = c + 3;           // my next target
-          if (nt2 < nchunks) {
-            issue(d, m, nt2);
-          } else if (more) {
-            if (nt2 - nchunks < 2) aim(m, nxt);   // first target on the next tile
-            issue(d, m, nt2 - nchunks);
-          }
+        WSTAMP(8, 3 * c + 2);
+        const int nt2 = c + 3;
+        if (nt2 < nchunks) {
+          issue(S, nt2);
+        } else if (more) {
+          if (nt2 == nchunks) aim(am, nxt);     // phase n-3: from here on every load is for the next tile
+          issue(S, nt2 - nchunks);
         }
+      };
+      const int gper = nchunks >= 8 ? 1 : 2;   // output groups copied per chunk pair
+      for (int c = 0; c < nchunks; c += 2) {
+        if (c == 0 && ht == 0 && more) post(s_wr, ticket_pre);
+        if (have_y) {   // outputs of the previous tile (Y is rewritten at this tile's fold)
+          for (int g = (c >> 1) * gper; g < ((c >> 1) + 1) * gper && g < 4; ++g) store_group(oa, g);
+        }
+        phase(S1, c);        // even phase: target c+1 is odd
+        phase(S0, c + 1);    // odd phase: target c+2 is even
       }
       if (ht == 0 && more && read_slot(s_wr).item < a.ntiles) ticket_pre = next_ticket();
       aim_out(oa, cur);
@@ -306,7 +347,15 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
       s_nxt = s_wr;
       s_wr = s_old == 0 ? 2 : s_old - 1;
     }
-    if (have_y) store_outputs(oa);
+    if (have_y) {
+      for (int g = 0; g < 4; ++g) store_group(oa, g);
+    }
+#if WB_STAMP
+    if (wave == 8) {
+      wb_stamps[blockIdx.x * 128 + lane] = ((long long*)(lds_raw + SLOTOFF + 64))[lane];
+      wb_stamps[blockIdx.x * 128 + 64 + lane] = ((long long*)(lds_raw + SLOTOFF + 64))[64 + lane];
+    }
+#endif
     if (ht == 0) {
       const unsigned long long done = atomicAdd(a.ticket + 1, 1ULL);
       if (done == (unsigned long long)gridDim.x - 1) {
@@ -362,13 +411,17 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
 #pragma unroll
   for (int f = 0; f < RING; ++f) fetch(Bq[f], soff_of(soff_phase, 0, f));
   int s_nxt = 1;
+  int tile_count = 0;
+  (void)tile_count;
   while (cur.item < a.ntiles) {
+    tile_count++;
     const Tile nxt = read_slot(s_nxt);
     const unsigned soff_phase_nxt =
         (unsigned)((nxt.item < a.ntiles ? nxt.item : cur.item) & (a.nphase - 1)) * (unsigned)a.u_phase_bytes;
     auto chunk_body = [&](auto first_tag, int chunk) {
       constexpr bool FIRST = decltype(first_tag)::value;
       const bool last = chunk + 1 == nchunks;
+      WSTAMP(0, 3 * chunk);
       unsigned zero_xi = 4, zero_nu = 4;
       if (MODE == 1) {
         const int blk = chunk / (nchunks >> 2);
@@ -420,16 +473,23 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
           const int f = pi + RING;
           const unsigned so = f < 8 ? soff_of(soff_phase, chunk, f)
                                     : (last ? soff_of(soff_phase_nxt, 0, f - 8) : soff_of(soff_phase, chunk + 1, f - 8));
-          fetch(Bq[pi % RING], so);
+          // a structurally zero position of THIS chunk is never multiplied: its fragments are not
+          // fetched at all (the vector-memory path, 64 B/clk per CU, is what bounds this kernel).
+          // Steps of the next chunk / tile (f >= 8) start at a position that is never zero for
+          // f - 8 < RING only in MODE 1; they are fetched unconditionally.
+          if (!(ZSKIP && f < 8 && is_zero(f))) fetch(Bq[pi % RING], so);
         }
       }
+      WSTAMP(0, 3 * chunk + 1);
       __syncthreads();  // B_chunk
+      WSTAMP(0, 3 * chunk + 2);
     };
     chunk_body(std::true_type{}, 0);
     for (int chunk = 1; chunk < nchunks; ++chunk) chunk_body(std::false_type{}, chunk);
     soff_phase = soff_phase_nxt;
 
     // ---- inverse transform (as conv_wino.hip) -----------------------------------------------
+    WSTAMP(0, 60);
     {
       float* yown = yreg + ((4 * (2 * ph) + nt) * 32 + 4 * h) * WP + l31;
       float* yoth = yreg + ((4 * (2 * (ph ^ 1)) + nt) * 32 + 4 * h) * WP + l31;
@@ -443,6 +503,7 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) yown[(4 * j * 32 + (e & 3) + 8 * (e >> 2)) * WP] = own[e];
       }
+      WSTAMP(0, 61);
       __syncthreads();  // E1
       auto finish_rows = [&](auto act_tag) {
         constexpr int ACT = decltype(act_tag)::value;
@@ -476,7 +537,9 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
       else
         finish_rows(std::integral_constant<int, DSIC_ACT_NONE>{});
     }
+    WSTAMP(0, 62);
     __syncthreads();  // E2
+    WSTAMP(0, 63);
     cur = nxt;
     s_nxt = s_nxt == 2 ? 0 : s_nxt + 1;
   }
@@ -510,6 +573,12 @@ __global__ void split_u_kernel(const float* __restrict__ u32, unsigned short* __
 }  // namespace dsic
 
 using namespace dsic;
+
+#if WB_STAMP
+extern "C" int dsic_debug_wb_stamps(long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(wb::wb_stamps), sizeof(long long) * 256 * 128) == hipSuccess ? 0 : 2;
+}
+#endif
 
 extern "C" int dsic_wino_bf16_planes(void) { return wb::P; }
 
