@@ -15,9 +15,11 @@ namespace dsic {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-template <int C>
+// U8: the image arrives as uint8 HWC (a decoded PNG/JPEG, PIL / numpy layout) and is converted on
+// the fly exactly like torchvision's to_tensor (code/modelv2/modelseval.py:66-67): float(v) / 255.0f.
+template <int C, bool U8 = false>
 __global__ __launch_bounds__(256, 2) void conv_first_kernel(
-    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    const void* __restrict__ xv, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ beta, const float* __restrict__ gamma, float* __restrict__ out, int B,
     int H, int W, int Cout, int act, int tiles_x, int tiles_y, int s2d) {
   constexpr int K = 9 * C;
@@ -65,13 +67,24 @@ __global__ __launch_bounds__(256, 2) void conv_first_kernel(
   }
 
   // stage the window (zero padded)
-  const float* xin = x + (size_t)n * C * H * W;
-  for (int i = tid; i < C * WH * WW; i += 256) {
-    const int c = i / (WH * WW), r = (i / WW) % WH, xx = i % WW;
-    const int gy = oy0 - 1 + r, gx = ox0 - 1 + xx;
-    float v = 0.f;
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = xin[((size_t)c * H + gy) * W + gx];
-    lds[(c * WH + r) * RS + xx] = v;
+  if (U8) {
+    const unsigned char* xin = (const unsigned char*)xv + (size_t)n * C * H * W;
+    for (int i = tid; i < C * WH * WW; i += 256) {
+      const int c = i % C, xx = (i / C) % WW, r = i / (C * WW);   // channel fastest: contiguous HWC bytes
+      const int gy = oy0 - 1 + r, gx = ox0 - 1 + xx;
+      float v = 0.f;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = (float)xin[((size_t)gy * W + gx) * C + c] / 255.0f;
+      lds[(c * WH + r) * RS + xx] = v;
+    }
+  } else {
+    const float* xin = (const float*)xv + (size_t)n * C * H * W;
+    for (int i = tid; i < C * WH * WW; i += 256) {
+      const int c = i / (WH * WW), r = (i / WW) % WH, xx = i % WW;
+      const int gy = oy0 - 1 + r, gx = ox0 - 1 + xx;
+      float v = 0.f;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = xin[((size_t)c * H + gy) * W + gx];
+      lds[(c * WH + r) * RS + xx] = v;
+    }
   }
   __syncthreads();
 
@@ -138,16 +151,35 @@ __global__ __launch_bounds__(256, 2) void conv_first_kernel(
   }
 }
 
+// to_tensor (modelseval.py:66-67, eval_selfcontained.py:58-59): uint8 HWC image -> float32 CHW in [0,1]
+__global__ void u8hwc_to_f32nchw_kernel(const unsigned char* __restrict__ in, float* __restrict__ out, int C,
+                                        int HW, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [B][C][HW]
+  if (i >= total) return;
+  const int64_t p = i % HW;
+  const int64_t bc = i / HW;
+  const int c = (int)(bc % C);
+  const int64_t b = bc / C;
+  out[i] = (float)in[(b * HW + p) * C + c] / 255.0f;
+}
+
 }  // namespace dsic
 
 using namespace dsic;
 
-// conv(Cimg,Cout,3,1) (+GDN/ReLU) from the NCHW image to NHWC features
-// (layers.py:51).  w is the REFERENCE weight tensor [Cout][Cimg][3][3], unpacked.
-extern "C" int dsic_conv_first_nchw(const float* x_nchw, const float* w_oihw, const float* bias,
-                                    const float* beta, const float* gamma, float* out_nhwc, int B,
-                                    int Cimg, int H, int W, int Cout, int act, int s2d, void* stream) {
-  DSIC_REQUIRE(x_nchw && w_oihw && bias && out_nhwc, "conv_first: null pointer");
+extern "C" int dsic_image_u8hwc_to_f32nchw(const unsigned char* x_u8_nhwc, float* out_nchw, int B, int C, int H,
+                                           int W, void* stream) {
+  DSIC_REQUIRE(x_u8_nhwc && out_nchw && B > 0 && C > 0 && H > 0 && W > 0, "image_u8hwc_to_f32nchw: bad argument");
+  const int64_t total = (int64_t)B * C * H * W;
+  hipLaunchKernelGGL(u8hwc_to_f32nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     x_u8_nhwc, out_nchw, C, H * W, total);
+  return check_launch("image_u8hwc_to_f32nchw");
+}
+
+static int conv_first_launch(const void* x, bool u8, const float* w_oihw, const float* bias, const float* beta,
+                             const float* gamma, float* out_nhwc, int B, int Cimg, int H, int W, int Cout, int act,
+                             int s2d, void* stream) {
+  DSIC_REQUIRE(x && w_oihw && bias && out_nhwc, "conv_first: null pointer");
   DSIC_REQUIRE(B > 0 && H > 0 && W > 0, "conv_first: empty tensor");
   DSIC_REQUIRE(Cimg == 3 || Cimg == 4, "conv_first: Cimg=%d must be 3 or 4", Cimg);
   DSIC_REQUIRE(Cout > 0 && Cout <= 128 && Cout % 4 == 0, "conv_first: Cout=%d must be a multiple of 4, <= 128", Cout);
@@ -157,11 +189,31 @@ extern "C" int dsic_conv_first_nchw(const float* x_nchw, const float* w_oihw, co
   const int tx = ceil_div(W, 16), ty = ceil_div(H, 8);
   DSIC_REQUIRE((int64_t)tx * ty * B < ((int64_t)1 << 31), "conv_first: grid too large");
   dim3 grid(tx * ty * B), block(256);
-  if (Cimg == 3)
-    hipLaunchKernelGGL(conv_first_kernel<3>, grid, block, 0, (hipStream_t)stream, x_nchw, w_oihw, bias, beta,
-                       gamma, out_nhwc, B, H, W, Cout, act, tx, ty, s2d);
-  else
-    hipLaunchKernelGGL(conv_first_kernel<4>, grid, block, 0, (hipStream_t)stream, x_nchw, w_oihw, bias, beta,
-                       gamma, out_nhwc, B, H, W, Cout, act, tx, ty, s2d);
+  hipStream_t st = (hipStream_t)stream;
+#define DSIC_FIRST(CC, UU)                                                                                        \
+  hipLaunchKernelGGL((conv_first_kernel<CC, UU>), grid, block, 0, st, x, w_oihw, bias, beta, gamma, out_nhwc, B, H, \
+                     W, Cout, act, tx, ty, s2d)
+  if (Cimg == 3) {
+    if (u8) DSIC_FIRST(3, true); else DSIC_FIRST(3, false);
+  } else {
+    if (u8) DSIC_FIRST(4, true); else DSIC_FIRST(4, false);
+  }
+#undef DSIC_FIRST
   return check_launch("conv_first");
+}
+
+// conv(Cimg,Cout,3,1) (+GDN/ReLU) from the NCHW image to NHWC features
+// (layers.py:51).  w is the REFERENCE weight tensor [Cout][Cimg][3][3], unpacked.
+extern "C" int dsic_conv_first_nchw(const float* x_nchw, const float* w_oihw, const float* bias,
+                                    const float* beta, const float* gamma, float* out_nhwc, int B,
+                                    int Cimg, int H, int W, int Cout, int act, int s2d, void* stream) {
+  return conv_first_launch(x_nchw, false, w_oihw, bias, beta, gamma, out_nhwc, B, Cimg, H, W, Cout, act, s2d, stream);
+}
+
+// The same layer straight from the decoded uint8 HWC image: to_tensor (modelseval.py:66-67) fused
+// into the window staging, a quarter of the float image's bytes over PCIe and from HBM.
+extern "C" int dsic_conv_first_u8hwc(const unsigned char* x_u8_nhwc, const float* w_oihw, const float* bias,
+                                     const float* beta, const float* gamma, float* out_nhwc, int B, int Cimg,
+                                     int H, int W, int Cout, int act, int s2d, void* stream) {
+  return conv_first_launch(x_u8_nhwc, true, w_oihw, bias, beta, gamma, out_nhwc, B, Cimg, H, W, Cout, act, s2d, stream);
 }

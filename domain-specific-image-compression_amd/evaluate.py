@@ -30,11 +30,20 @@ def combine_bands(bands, want_uint8=False):
 
 @torch.no_grad()
 def evaluate_batch(model, x, weights=(0.3, 0.5, 0.2)):
-    """x: [B,C,h,w] in [0,1] on the GPU, any size >= 16.  Returns a list of per-image dicts with the
-    columns of the reference's per-image CSV (modelseval.py:187-199): bpp, mse, psnr, msssim."""
+    """x: [B,C,h,w] float32 in [0,1] on the GPU, any size >= 16 — or the decoded images as uint8
+    [B,h,w,C] (modelseval.py:164 `tensor_from_pil`: to_tensor runs on the GPU, fused into the first
+    layer when no padding is needed).  Returns a list of per-image dicts with the columns of the
+    reference's per-image CSV (modelseval.py:187-199): bpp, mse, psnr, msssim."""
+    x_u8 = None
+    if x.dtype == torch.uint8:
+        from . import ops
+        x_u8, x = x, ops.to_tensor_u8(x)                                    # :66-67
     B, C, h, w = x.shape
-    x_pad, _, _ = metrics.pad_to_multiple_tensor(x, 16)                     # :170
-    out = model(x_pad, quant_mode="round")                                  # :173
+    if x_u8 is not None and h % 16 == 0 and w % 16 == 0:
+        out = model(x_u8, quant_mode="round")                               # image bytes straight into g_a.0
+    else:
+        x_pad, _, _ = metrics.pad_to_multiple_tensor(x, 16)                 # :170
+        out = model(x_pad, quant_mode="round")                              # :173
     x_hat = out["x_hat"][:, :, :h, :w].contiguous()                         # :178 (clamp fused below)
     bpp = (out.sums.sum(dim=1) / float(h * w)).cpu().numpy()                # :181, un-padded pixel count
     mse = metrics.mse_per_image(x_hat, x, clamp_a=True).cpu().numpy()       # :184

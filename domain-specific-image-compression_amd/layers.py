@@ -242,10 +242,15 @@ class _Chain(nn.Sequential):
         runs as the dedicated first-layer kernel (K = 9*Cimg, no channel padding)."""
         mods = list(self)
         m = mods[0] if mods else None
-        if (isinstance(m, Conv2d) and m.kernel_size == 3 and m.stride == 1 and m.in_channels in (3, 4)
-                and m.out_channels <= 128 and m.out_channels % 4 == 0 and x_nchw.shape[1] == m.in_channels):
+        u8 = x_nchw.dtype == torch.uint8          # decoded image bytes [B,H,W,C]: to_tensor is fused into the kernel
+        cin = x_nchw.shape[3] if u8 else x_nchw.shape[1]
+        first_ok = (isinstance(m, Conv2d) and m.kernel_size == 3 and m.stride == 1 and m.in_channels in (3, 4)
+                    and m.out_channels <= 128 and m.out_channels % 4 == 0 and cin == m.in_channels)
+        if u8 and not first_ok:
+            x_nchw, u8 = ops.to_tensor_u8(x_nchw), False
+        if first_ok:
             nxt = mods[1] if len(mods) > 1 else None
-            H, W = x_nchw.shape[2], x_nchw.shape[3]
+            H, W = (x_nchw.shape[1], x_nchw.shape[2]) if u8 else (x_nchw.shape[2], x_nchw.shape[3])
             if isinstance(nxt, GDN) and not nxt.inverse:
                 beta, gamma = nxt.effective()
                 s2d = self._wants_s2d(mods, 2, H, W)

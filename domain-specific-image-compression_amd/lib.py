@@ -49,6 +49,8 @@ SIGNATURES = {
     "dsic_conv_transpose2d_wino_bf16_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
                                                      _P, _P]),
     "dsic_conv_first_nchw": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "dsic_conv_first_u8hwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "dsic_image_u8hwc_to_f32nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "dsic_conv_transpose2d_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int,
                                            c_int, c_int, _P]),
     "dsic_conv_transpose2d_image": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -50,7 +50,9 @@ class CompressionModel(nn.Module):
 
     @torch.no_grad()
     def forward(self, x, quant_mode="noise", collect_taps=False, after_rate=None):
-        """model.py:37-72.  x: [B,C,H,W] float32 on the GPU, H and W multiples of 16.
+        """model.py:37-72.  x: [B,C,H,W] float32 on the GPU, H and W multiples of 16 — or the decoded
+        image bytes, uint8 [B,H,W,C] (PIL / numpy layout): torchvision's to_tensor
+        (modelseval.py:66-67) is then fused into the first layer's kernel.
 
         `after_rate(partial)` (optional) is called once the latents, sigma/nu and
         the rate terms are enqueued and BEFORE synthesis is launched, so a caller
@@ -59,7 +61,10 @@ class CompressionModel(nn.Module):
             raise ValueError(f"Unknown quant mode: {quant_mode}")
         if x.dim() != 4:
             raise ValueError(f"expected [N,C,H,W], got {tuple(x.shape)}")
-        B, _, H, W = x.shape
+        if x.dtype == torch.uint8:
+            B, H, W, _ = x.shape
+        else:
+            B, _, H, W = x.shape
         taps = [] if collect_taps else None
         y = self.g_a.forward_from_image(x, taps)           # [B,H/16,W/16,M]
         z = self.h_a.forward_nhwc(y, taps)                 # [B,.,.,N]

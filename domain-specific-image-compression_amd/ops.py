@@ -278,12 +278,38 @@ def conv3x3_wino_nhwc(x, u_packed, bias, Cout, act=ACT_NONE, beta=None, gamma=No
     return out
 
 
+def to_tensor_u8(x_u8_nhwc: torch.Tensor) -> torch.Tensor:
+    """torchvision to_tensor (modelseval.py:66-67): uint8 [B,H,W,C] on the GPU -> float32 [B,C,H,W] in [0,1]."""
+    if not x_u8_nhwc.is_cuda or x_u8_nhwc.dtype != torch.uint8 or x_u8_nhwc.dim() != 4:
+        raise TypeError("to_tensor_u8: expected a uint8 [B,H,W,C] tensor on the GPU")
+    x = x_u8_nhwc.contiguous()
+    B, H, W, C = x.shape
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().dsic_image_u8hwc_to_f32nchw(_p(x), _p(out), B, C, H, W, _stream()), "to_tensor_u8")
+    return out
+
+
 def conv_first_nchw(x, w, bias, act=ACT_NONE, beta=None, gamma=None, s2d_out=False):
-    """conv(Cimg,Cout,3,1) + fused activation from the NCHW image to NHWC (layers.py:51)."""
-    x = _f32c(x, "conv_first_nchw")
+    """conv(Cimg,Cout,3,1) + fused activation from the image to NHWC (layers.py:51).
+    x: float32 NCHW in [0,1] (the reference's tensor contract), or uint8 NHWC image bytes
+    (to_tensor fused into the kernel)."""
     w = _f32c(w, "conv_first_nchw")
-    B, C, H, W = x.shape
     Cout = w.shape[0]
+    if x.dtype == torch.uint8:
+        if not x.is_cuda:
+            raise RuntimeError(f"conv_first_nchw: expected a tensor on the GPU (no CPU fallback), got {x.device}")
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        shape = (B, H // 2, W // 2, 4 * Cout) if s2d_out else (B, H, W, Cout)
+        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+        L = _lib.load()
+        _timed(f"conv_first_kernel<{C}>", 2.0 * B * H * W * Cout * C * 9,
+               lambda: _lib.check(L.dsic_conv_first_u8hwc(_p(x), _p(w), _p(bias), _p(beta), _p(gamma), _p(out), B, C,
+                                                          H, W, Cout, act, int(bool(s2d_out)), _stream()),
+                                  "conv_first_u8hwc"))
+        return out
+    x = _f32c(x, "conv_first_nchw")
+    B, C, H, W = x.shape
     shape = (B, H // 2, W // 2, 4 * Cout) if s2d_out else (B, H, W, Cout)
     out = torch.empty(shape, dtype=torch.float32, device=x.device)
     L = _lib.load()

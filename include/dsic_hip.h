@@ -169,6 +169,17 @@ int dsic_conv_first_nchw(const float* x_nchw, const float* w_oihw,
                          const float* gamma, float* out_nhwc, int B, int Cimg,
                          int H, int W, int Cout, int act, int s2d_out,
                          void* stream);
+/* The same layer from the decoded image bytes: x_u8_nhwc [B][H][W][Cimg] uint8 (PIL / numpy layout);
+ * to_tensor (code/modelv2/modelseval.py:66-67, eval_selfcontained.py:58-59: float(v)/255) is fused
+ * into the kernel's window staging. */
+int dsic_conv_first_u8hwc(const unsigned char* x_u8_nhwc, const float* w_oihw,
+                          const float* bias, const float* beta, const float* gamma,
+                          float* out_nhwc, int B, int Cimg, int H, int W, int Cout,
+                          int act, int s2d, void* stream);
+/* to_tensor alone: uint8 [B][H][W][C] -> float32 [B][C][H][W] in [0,1] (the x of the metrics). */
+int dsic_image_u8hwc_to_f32nchw(const unsigned char* x_u8_nhwc, float* out_nchw,
+                                int B, int C, int H, int W, void* stream);
+
 
 /* ConvTranspose2d(Cin,Cout,5,2,2,output_padding=1) + optional IGDN/ReLU.
  * in NHWC [B,H,W,Cin] -> out NHWC [B,2H,2W,Cout]. */

@@ -134,3 +134,32 @@ def test_submodules_are_callable_like_the_reference():
     fg = FactorizedGaussian(6).cuda()
     fg.log_sigma.copy_(torch.from_numpy(u["gauss/log_sigma"]))
     np.testing.assert_allclose(fg.neg_log2_prob(xs).cpu().numpy(), u["gauss/bits"], rtol=2e-5)
+
+
+def test_uint8_image_ingest_equals_to_tensor_path():
+    """modelseval.py:66-67,164 / eval_selfcontained.py:58-59: images arrive as uint8 HWC and become
+    float32 CHW / 255 (torchvision to_tensor).  The GPU to_tensor and the first layer's fused uint8
+    path give exactly the float path's results."""
+    from dsic_amd import evaluate, ops
+    from dsic_amd.model import CompressionModel
+    for C, H, W in ((3, 64, 96), (4, 48, 32)):
+        sd = S.make_state_dict(seed=1, in_ch=C)
+        m = CompressionModel(N=128, M=192, spatial_params=False, min_nu=2, max_nu=100.0, in_ch=C)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        m = m.cuda().eval()
+        u8 = torch.from_numpy((S.make_patches(700, 2, H, W, C) * 255.0 + 0.5).astype(np.uint8)).permute(0, 2, 3, 1).contiguous()
+        want = u8.permute(0, 3, 1, 2).to(torch.float32).div(255)             # what to_tensor computes
+        xf = ops.to_tensor_u8(u8.cuda())
+        assert torch.equal(xf.cpu(), want)
+        a = m(xf, quant_mode="round")
+        b = m(u8.cuda(), quant_mode="round")
+        for k in ("y", "y_tilde", "z_tilde", "x_hat", "nll_y"):
+            assert torch.equal(a[k], b[k]), k
+        assert torch.equal(a.sums, b.sums)
+        rows_f = evaluate.evaluate_batch(m, xf)
+        rows_u = evaluate.evaluate_batch(m, u8.cuda())
+        assert rows_f == rows_u
+        # an image that needs reflect padding goes through to_tensor + pad (modelseval.py:170)
+        odd = u8[:, : H - 5, : W - 3].contiguous().cuda()
+        rows_o = evaluate.evaluate_batch(m, odd)
+        assert rows_o == evaluate.evaluate_batch(m, ops.to_tensor_u8(odd))
