@@ -20,10 +20,11 @@
 //     the two V planes (2 ds_read_b128), takes the two U planes from its register ring
 //     (transformed weights, bf16, [pos][chunk][plane][CoutP][16], streamed from L2) and issues
 //     3 MFMAs.
-//   * the four helper waves (one per SIMD) share every chunk: thread = (Winograd tile, channel quad,
-//     half of the positions); it loads three rows of the 4x4 patch, applies B^T d B in fp32, splits
-//     into the bf16 planes and stores them into the V buffer the MFMA waves are not reading.  Two
-//     patches per thread are in flight, so a load has two MFMA phases to arrive.
+//   * the four helper waves (one per SIMD) share every chunk.  The tile's 18x10-pixel input window is
+//     loaded once (3 float4 per thread, two phases ahead) and staged in LDS (2 x 11.5 KB); thread =
+//     (Winograd tile, channel quad, half of the positions) then reads three rows of its 4x4 patch
+//     from there, applies B^T d B in fp32, splits into the bf16 planes and stores them into the V
+//     buffer the MFMA waves are not reading.
 // Tile hand-out, the fold through LDS and the fused epilogue are those of conv_wino.hip.
 #include <stdlib.h>
 
@@ -67,6 +68,8 @@ struct Args {
   int s2d_in, s2d;
   int tiles_x, tiles_y, ntiles;
   int nt_out;
+  int dbg;  // DSIC_WB_DBG ablation bits (diagnostic, wrong results): 1 U from one hot line, 2 no input loads,
+            // 4 no transform/V stores, 8 no fold, 16 no MFMAs
 };
 
 constexpr int P = WB_PLANES;
@@ -79,7 +82,11 @@ constexpr int WP = 36;                          // floats per (plane, tile) row 
 constexpr int YOFF = 2 * VBUFB;                 // byte offset of the output region
 constexpr int YBYTES = 16 * 32 * WP * 4;        // 73728
 constexpr int SLOTOFF = YOFF + YBYTES;
-constexpr int LDS_TOTAL = SLOTOFF + 64 + (WB_STAMP ? 1024 : 0);
+constexpr int WINW = 18, WINH = 10;              // input window of a 16x8-pixel tile (halo 1)
+constexpr int WINB = WINW * WINH * CK * 4;      // fp32 window of one chunk: 11520 bytes
+constexpr int STAGEOFF = SLOTOFF + 64;          // two window buffers
+constexpr int STAMPOFF = STAGEOFF + 2 * WINB;
+constexpr int LDS_TOTAL = STAMPOFF + (WB_STAMP ? 1024 : 0);
 constexpr int THREADS = 768;
 constexpr int RING = 2;                         // position-steps of U fragments in flight per MFMA wave
 
@@ -91,7 +98,7 @@ __device__ long long wb_stamps[256 * 128];
   do {                                                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                             \
     if (lane == 0 && wave == (w) && tile_count == WB_STAMP_TILE && (i) < 64)                       \
-      ((long long*)(lds_raw + SLOTOFF + 64))[((w) == 0 ? 0 : 64) + (i)] = __builtin_amdgcn_s_memtime(); \
+      ((long long*)(lds_raw + STAMPOFF))[((w) == 0 ? 0 : 64) + (i)] = __builtin_amdgcn_s_memtime(); \
     __builtin_amdgcn_sched_barrier(0);                                                             \
   } while (0)
 #else
@@ -153,10 +160,7 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
     // Every chunk is produced by all four helper waves (one per SIMD, so the VALU work is spread
     // evenly beside the MFMA waves): thread = (Winograd tile pt, channel quad pq of the 16-channel
     // chunk, row half hx).  Half hx owns the positions xi in {2hx, 2hx+1}: they need only three of
-    // the four patch rows (xi 0: r0-r2, 1: r1+r2 | 2: r2-r1, 3: r1-r3), i.e. 12 float4 loads.
-    // Two patches are in flight per thread (sets S0, S1): target chunk k lives in set k&1, is
-    // committed to V[k&1] during MFMA phase k-1, and the loads of target k+2 are issued into the
-    // same set right behind the barrier that ends that phase - two full phases before their use.
+    // the four patch rows (xi 0: r0-r2, 1: r1+r2 | 2: r2-r1, 3: r1-r3).
     const int ht = tid - 512;
     const int hx = __builtin_amdgcn_readfirstlane(ht >> 7);
     const int Cin = a.Cin;
@@ -176,37 +180,53 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
       const intx4 v = {item, tile - row * a.tiles_x, row % a.tiles_y, row / a.tiles_y};
       *(intx4*)(slots + 4 * s) = v;
     };
-    struct Patch {
-      floatx4 d[12];      // pixel rows hx, hx+1, hx+2 of the 4x4 patch, 4 columns each
-    };
-    // One aim serves both sets: every load issued before phase n-3 of a tile targets that tile,
-    // every load from phase n-3 on targets the next one (targets n, n+1, n+2 = its chunks 0, 1, 2).
-    struct Aim {
-      unsigned off[12];   // byte offsets of the 12 pixels inside the image (out of range = reads 0)
+    // Input side.  The 18x10-pixel window of the tile (halo 1; 16 channels of the chunk, fp32) is
+    // loaded ONCE from global memory - 720 float4 for 256 threads - and staged in LDS; every
+    // thread then reads its 3x4 patch from there.  (Loading the overlapping patches straight from
+    // global memory costs 12 loads per thread and chunk; the vector-memory path, not the MFMA, was
+    // then what bounded the kernel: -30 % kernel time with those loads removed.)
+    //   R[s]      window registers: the chunk that will be staged into window buffer s
+    //   phase c:  stage W[c&1] <- R[c&1] (chunk c+2); commit target c+1 from W[(c+1)&1] to V[(c+1)&1];
+    //             barrier; issue R[c&1] <- chunk c+4
+    // so a global load has two phases to arrive, a staged window one barrier to become visible.
+    struct WinAim {
+      unsigned off[3];   // byte offsets of this thread's (pixel, quad) items inside the image (out of range = 0)
       __amdgpu_buffer_rsrc_t rsrc;
     };
-    Aim am;
-    auto aim = [&](Aim& m, const Tile& t) {
-      const int gy0 = t.ty * 8 + 2 * pty - 1 + hx, gx0 = t.tx * 16 + 2 * ptx - 1;
+    WinAim am;
+    unsigned stage_off[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int i = ht + 256 * j;
+      stage_off[j] = (unsigned)((i >> 2) * (CK * 4) + (i & 3) * 16);
+    }
+    auto aim = [&](WinAim& m, const Tile& t) {
       m.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)t.n * a.H * a.W * Cin), 0,
                                                  a.H * a.W * Cin * 4, 0x00020000);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int gy = gy0 + i;
-        const bool yok = gy >= 0 && gy < a.H;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int gx = gx0 + k;
-          const bool ok = yok && gx >= 0 && gx < a.W;
-          m.off[i * 4 + k] = ok ? (unsigned)(((gy * a.W + gx) * Cin + 4 * pq) * 4) : 0x80000000u;
-        }
+      for (int j = 0; j < 3; ++j) {
+        const int i = ht + 256 * j;
+        const int pix = i >> 2, q = i & 3;
+        const int wy = pix / WINW, wx = pix - wy * WINW;
+        const int gy = t.ty * 8 - 1 + wy, gx = t.tx * 16 - 1 + wx;
+        const bool ok = i < WINW * WINH * 4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        m.off[j] = ok ? (unsigned)(((gy * a.W + gx) * Cin + 4 * q) * 4) : 0x80000000u;
       }
     };
-    auto issue = [&](Patch& m, int chunk) {
+    auto issue = [&](floatx4 (&r)[3], int chunk) {
+      if (a.dbg & 2) return;
 #pragma unroll
-      for (int p = 0; p < 12; ++p)
-        m.d[p] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(am.rsrc, am.off[p], chunk * (CK * 4), 0));
+      for (int j = 0; j < 3; ++j)
+        r[j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(am.rsrc, am.off[j], chunk * (CK * 4), 0));
     };
+    auto stage = [&](const floatx4 (&r)[3], int wbuf) {
+      unsigned char* wb = lds_raw + STAGEOFF + wbuf * WINB;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (j < 2 || ht < WINW * WINH * 4 - 512) *(floatx4*)(wb + stage_off[j]) = r[j];
+    };
+    // this thread's patch inside a staged window: rows 2*pty+hx .. +2, columns 2*ptx .. +3, quad pq
+    const int patch0 = ((2 * pty + hx) * WINW + 2 * ptx) * (CK * 4) + pq * 16;
     // fp32 value -> bf16 planes: hi = bf16(v), mid = bf16(v - hi) (, lo = bf16(v - hi - mid))
     auto split_store = [&](floatx4 v, unsigned char* dst) {
       const unsigned h0 = cvt_pk_bf16(v[0], v[1]), h1 = cvt_pk_bf16(v[2], v[3]);
@@ -219,13 +239,17 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
         *(uintx2*)(dst + 2 * PLANEB) = uintx2{cvt_pk_bf16(r0, r1), cvt_pk_bf16(r2, r3)};
       }
     };
-    // B^T d B for this thread's two xi rows, into V buffer vb (0/1)
-    auto commit = [&](const Patch& m, int vb) {
+    // B^T d B for this thread's two xi rows: window buffer wbuf -> V buffer vb
+    auto commit = [&](int wbuf, int vb) {
+      if (a.dbg & 4) return;
+      const unsigned char* src = lds_raw + STAGEOFF + wbuf * WINB + patch0;
       unsigned char* dst = vmine + vb * VBUFB;
       floatx4 xlo[4], xhi[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const floatx4 ra = m.d[0 * 4 + k], rb = m.d[1 * 4 + k], rc = m.d[2 * 4 + k];
+        const floatx4 ra = *(const floatx4*)(src + (0 * WINW + k) * (CK * 4));
+        const floatx4 rb = *(const floatx4*)(src + (1 * WINW + k) * (CK * 4));
+        const floatx4 rc = *(const floatx4*)(src + (2 * WINW + k) * (CK * 4));
         if (hx == 0) {   // wave-uniform
           xlo[k] = ra - rc;   // xi 0: r0 - r2
           xhi[k] = rb + rc;   // xi 1: r1 + r2
@@ -291,14 +315,18 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
     }
     __syncthreads();  // P0
     Tile cur = read_slot(0);
-    Patch S0, S1;
+    floatx4 R0[3], R1[3];
     int ticket_pre = a.ntiles;
     aim(am, cur);
-    issue(S0, 0);
-    issue(S1, 1);
-    commit(S0, 0);               // V[0] = (cur, 0)
-    issue(S0, 2);
+    issue(R0, 0);
+    issue(R1, 1);
+    stage(R0, 0);
+    stage(R1, 1);
+    issue(R0, 2);
+    issue(R1, 3);
     if (ht == 0 && read_slot(1).item < a.ntiles) ticket_pre = next_ticket();
+    __syncthreads();  // P1: windows of chunks 0 and 1 are staged
+    commit(0, 0);                // V[0] = (cur, 0)
     __syncthreads();  // P
     int s_nxt = 1, s_wr = 2;
     OutAim oa;
@@ -312,20 +340,20 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
       const Tile nxt = read_slot(s_nxt);
       const bool more = nxt.item < a.ntiles;
       tile_count++;
-      // one phase: commit target c+1 (set S, buffer (c+1)&1), barrier, issue target c+3 into S
-      auto phase = [&](Patch& S, int c) {
-        const int tgt = c + 1;
+      // one phase (tile-local chunk c; targets past the last chunk belong to the next tile)
+      auto phase = [&](floatx4 (&R)[3], int c) {
         WSTAMP(8, 3 * c);
-        if (tgt < nchunks || more) commit(S, tgt & 1);
+        if (c + 2 < nchunks || more) stage(R, c & 1);              // window of chunk c+2
+        if (c + 1 < nchunks || more) commit((c + 1) & 1, (c + 1) & 1);   // target c+1
         WSTAMP(8, 3 * c + 1);
         __syncthreads();  // B_c
         WSTAMP(8, 3 * c + 2);
-        const int nt2 = c + 3;
-        if (nt2 < nchunks) {
-          issue(S, nt2);
+        const int k4 = c + 4;
+        if (k4 < nchunks) {
+          issue(R, k4);
         } else if (more) {
-          if (nt2 == nchunks) aim(am, nxt);     // phase n-3: from here on every load is for the next tile
-          issue(S, nt2 - nchunks);
+          if (k4 == nchunks) aim(am, nxt);      // phase n-4: from here on every load is for the next tile
+          issue(R, k4 - nchunks);
         }
       };
       const int gper = nchunks >= 8 ? 1 : 2;   // output groups copied per chunk pair
@@ -334,8 +362,8 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
         if (have_y) {   // outputs of the previous tile (Y is rewritten at this tile's fold)
           for (int g = (c >> 1) * gper; g < ((c >> 1) + 1) * gper && g < 4; ++g) store_group(oa, g);
         }
-        phase(S1, c);        // even phase: target c+1 is odd
-        phase(S0, c + 1);    // odd phase: target c+2 is even
+        phase(R0, c);
+        phase(R1, c + 1);
       }
       if (ht == 0 && more && read_slot(s_wr).item < a.ntiles) ticket_pre = next_ticket();
       aim_out(oa, cur);
@@ -352,8 +380,8 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
     }
 #if WB_STAMP
     if (wave == 8) {
-      wb_stamps[blockIdx.x * 128 + lane] = ((long long*)(lds_raw + SLOTOFF + 64))[lane];
-      wb_stamps[blockIdx.x * 128 + 64 + lane] = ((long long*)(lds_raw + SLOTOFF + 64))[64 + lane];
+      wb_stamps[blockIdx.x * 128 + lane] = ((long long*)(lds_raw + STAMPOFF))[lane];
+      wb_stamps[blockIdx.x * 128 + 64 + lane] = ((long long*)(lds_raw + STAMPOFF))[64 + lane];
     }
 #endif
     if (ht == 0) {
@@ -394,6 +422,7 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
   floatx16 acc[8];
   bf16x8 Bq[RING][P];
   __syncthreads();  // P0
+  __syncthreads();  // P1
   __syncthreads();  // P
   Tile cur = read_slot(0);
   const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
@@ -404,6 +433,7 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
     return phase_off + (unsigned)(ph * 8 + pos_of(pi)) * pos_b + (unsigned)chunk * chunk_b;
   };
   auto fetch = [&](bf16x8 (&dst)[P], unsigned so) {
+    if (a.dbg & 1) so = 0;
 #pragma unroll
     for (int q = 0; q < P; ++q)
       dst[q] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(urs, ulane, so + (unsigned)q * plane_b, 0));
@@ -448,7 +478,7 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
       for (int pi = 0; pi < 8; ++pi) {
         const int p0 = pos_of(pi);
         const bool live = !ZSKIP || !is_zero(pi);  // wave-uniform
-        if (live) {
+        if (live && !(a.dbg & 16)) {
           const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           floatx16 c = FIRST ? zero : acc[p0];
           if (P == 3) {  // small terms first
@@ -490,7 +520,9 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
 
     // ---- inverse transform (as conv_wino.hip) -----------------------------------------------
     WSTAMP(0, 60);
-    {
+    if (a.dbg & 8) {
+      __syncthreads();
+    } else {
       float* yown = yreg + ((4 * (2 * ph) + nt) * 32 + 4 * h) * WP + l31;
       float* yoth = yreg + ((4 * (2 * (ph ^ 1)) + nt) * 32 + 4 * h) * WP + l31;
       floatx16 send[2];
@@ -631,6 +663,10 @@ static int wb_launch(wb::Args& a, hipStream_t st) {
       return DSIC_EHIP;
     }
     attr_set[dev] = true;
+  }
+  {
+    const char* d = getenv("DSIC_WB_DBG");
+    a.dbg = d ? atoi(d) : 0;
   }
   static int max_grid = 0;
   if (max_grid == 0) {
