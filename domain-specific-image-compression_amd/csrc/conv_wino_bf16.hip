@@ -38,6 +38,16 @@
 #ifndef WB_STAMP
 #define WB_STAMP 0   // diagnostic: cycle stamps of MFMA wave 0 and helper wave 8 for one tile (tools/wb_stamps.py)
 #endif
+#ifndef WB_ABL
+#define WB_ABL 0     // compile-time ablations (diagnostic, wrong results): 1 U from one hot line, 2 no input loads,
+#endif               // 4 no transform / V stores, 8 no fold, 16 no MFMAs.  (A run-time switch would put a branch
+                     // around every MFMA cluster and cost the loop its scheduling.)
+#ifndef WB_ADOUBLE
+#define WB_ADOUBLE 0
+#endif
+#ifndef WB_HPRIO
+#define WB_HPRIO 3
+#endif
 #ifndef WB_STAMP_TILE
 #define WB_STAMP_TILE 8
 #endif
@@ -68,8 +78,6 @@ struct Args {
   int s2d_in, s2d;
   int tiles_x, tiles_y, ntiles;
   int nt_out;
-  int dbg;  // DSIC_WB_DBG ablation bits (diagnostic, wrong results): 1 U from one hot line, 2 no input loads,
-            // 4 no transform/V stores, 8 no fold, 16 no MFMAs
 };
 
 constexpr int P = WB_PLANES;
@@ -161,6 +169,9 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
     // evenly beside the MFMA waves): thread = (Winograd tile pt, channel quad pq of the 16-channel
     // chunk, row half hx).  Half hx owns the positions xi in {2hx, 2hx+1}: they need only three of
     // the four patch rows (xi 0: r0-r2, 1: r1+r2 | 2: r2-r1, 3: r1-r3).
+    // the helpers' VALU stream fits beside the bf16 MFMAs (an MFMA holds the SIMD's vector issue for
+    // 8 of its 32 cycles); they are the longer pole of a phase, so they win the issue arbitration
+    __builtin_amdgcn_s_setprio(WB_HPRIO);
     const int ht = tid - 512;
     const int hx = __builtin_amdgcn_readfirstlane(ht >> 7);
     const int Cin = a.Cin;
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
       }
     };
     auto issue = [&](floatx4 (&r)[3], int chunk) {
-      if (a.dbg & 2) return;
+      if (WB_ABL & 2) return;
 #pragma unroll
       for (int j = 0; j < 3; ++j)
         r[j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(am.rsrc, am.off[j], chunk * (CK * 4), 0));
@@ -239,11 +250,14 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
         *(uintx2*)(dst + 2 * PLANEB) = uintx2{cvt_pk_bf16(r0, r1), cvt_pk_bf16(r2, r3)};
       }
     };
-    // B^T d B for this thread's two xi rows: window buffer wbuf -> V buffer vb
-    auto commit = [&](int wbuf, int vb) {
-      if (a.dbg & 4) return;
+    // B^T d B for this thread's two xi rows: window buffer wbuf -> V buffer vb.  zxi / znu: the
+    // structurally zero Winograd row / column of this chunk (4 = none; see the MFMA waves): those
+    // positions are never read, so they are neither transformed nor split nor stored.
+    auto commit = [&](int wbuf, int vb, unsigned zxi, unsigned znu) {
+      if (WB_ABL & 4) return;
       const unsigned char* src = lds_raw + STAGEOFF + wbuf * WINB + patch0;
       unsigned char* dst = vmine + vb * VBUFB;
+      const bool lo_live = zxi != (unsigned)(2 * hx), hi_live = zxi != (unsigned)(2 * hx + 1);   // wave-uniform
       floatx4 xlo[4], xhi[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -259,14 +273,32 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
         }
       }
       // columns: nu 0: x0-x2, 1: x1+x2, 2: x2-x1, 3: x1-x3
-      split_store(xlo[0] - xlo[2], dst + 0 * POSB);
-      split_store(xlo[1] + xlo[2], dst + 1 * POSB);
-      split_store(xlo[2] - xlo[1], dst + 2 * POSB);
-      split_store(xlo[1] - xlo[3], dst + 3 * POSB);
-      split_store(xhi[0] - xhi[2], dst + 4 * POSB);
-      split_store(xhi[1] + xhi[2], dst + 5 * POSB);
-      split_store(xhi[2] - xhi[1], dst + 6 * POSB);
-      split_store(xhi[1] - xhi[3], dst + 7 * POSB);
+      if (lo_live) {
+        if (znu != 0) split_store(xlo[0] - xlo[2], dst + 0 * POSB);
+        split_store(xlo[1] + xlo[2], dst + 1 * POSB);
+        split_store(xlo[2] - xlo[1], dst + 2 * POSB);
+        if (znu != 3) split_store(xlo[1] - xlo[3], dst + 3 * POSB);
+      }
+      if (hi_live) {
+        if (znu != 0) split_store(xhi[0] - xhi[2], dst + 4 * POSB);
+        split_store(xhi[1] + xhi[2], dst + 5 * POSB);
+        split_store(xhi[2] - xhi[1], dst + 6 * POSB);
+        if (znu != 3) split_store(xhi[1] - xhi[3], dst + 7 * POSB);
+      }
+    };
+    // zero row / column of tile-local chunk k of work item `item` (MODE 1: by channel block; MODE 2: by phase)
+    auto zero_of = [&](int item, int k, unsigned& zxi, unsigned& znu) {
+      zxi = 4;
+      znu = 4;
+      if (MODE == 1) {
+        const int blk = k / (nchunks >> 2);
+        if (blk >> 1) zxi = 3;
+        if (blk & 1) znu = 3;
+      } else if (MODE == 2) {
+        const int phase = item & 3;
+        if (phase >> 1) zxi = 0;
+        if (phase & 1) znu = 0;
+      }
     };
     struct OutAim {
       unsigned po[4];
@@ -326,7 +358,11 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
     issue(R1, 3);
     if (ht == 0 && read_slot(1).item < a.ntiles) ticket_pre = next_ticket();
     __syncthreads();  // P1: windows of chunks 0 and 1 are staged
-    commit(0, 0);                // V[0] = (cur, 0)
+    {
+      unsigned zxi, znu;
+      zero_of(cur.item, 0, zxi, znu);
+      commit(0, 0, zxi, znu);    // V[0] = (cur, 0)
+    }
     __syncthreads();  // P
     int s_nxt = 1, s_wr = 2;
     OutAim oa;
@@ -342,12 +378,17 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
       tile_count++;
       // one phase (tile-local chunk c; targets past the last chunk belong to the next tile)
       auto phase = [&](floatx4 (&R)[3], int c) {
-        WSTAMP(8, 3 * c);
+        WSTAMP(8, 4 * c);
         if (c + 2 < nchunks || more) stage(R, c & 1);              // window of chunk c+2
-        if (c + 1 < nchunks || more) commit((c + 1) & 1, (c + 1) & 1);   // target c+1
-        WSTAMP(8, 3 * c + 1);
+        WSTAMP(8, 4 * c + 1);
+        if (c + 1 < nchunks || more) {                                   // target c+1
+          unsigned zxi, znu;
+          if (c + 1 < nchunks) zero_of(cur.item, c + 1, zxi, znu); else zero_of(nxt.item, 0, zxi, znu);
+          commit((c + 1) & 1, (c + 1) & 1, zxi, znu);
+        }
+        WSTAMP(8, 4 * c + 2);
         __syncthreads();  // B_c
-        WSTAMP(8, 3 * c + 2);
+        WSTAMP(8, 4 * c + 3);
         const int k4 = c + 4;
         if (k4 < nchunks) {
           issue(R, k4);
@@ -433,7 +474,7 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
     return phase_off + (unsigned)(ph * 8 + pos_of(pi)) * pos_b + (unsigned)chunk * chunk_b;
   };
   auto fetch = [&](bf16x8 (&dst)[P], unsigned so) {
-    if (a.dbg & 1) so = 0;
+    if (WB_ABL & 1) so = 0;
 #pragma unroll
     for (int q = 0; q < P; ++q)
       dst[q] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(urs, ulane, so + (unsigned)q * plane_b, 0));
@@ -468,36 +509,53 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
         return xi == zero_xi || nu == zero_nu;
       };
       const unsigned char* vb = lds_raw + (chunk & 1) * VBUFB + aread;
+#if WB_ADOUBLE
+      // two sets of V fragments: the reads of step pi+1 are issued before the MFMAs of step pi
+      bf16x8 Aq[2][P];
+#pragma unroll
+      for (int q = 0; q < P; ++q) Aq[0][q] = *(const bf16x8*)(vb + pos_of(0) * POSB + q * PLANEB);
+#define AQ(q) Aq[pi & 1][q]
+#else
       // one set of V fragments: the reads of step pi+1 are issued right behind the MFMAs of step pi
       // (they land long after those MFMAs have read their sources); the second MFMA wave of the
       // SIMD covers the LDS latency
-      bf16x8 Aq[P];
+      bf16x8 Aq1[P];
 #pragma unroll
-      for (int q = 0; q < P; ++q) Aq[q] = *(const bf16x8*)(vb + pos_of(0) * POSB + q * PLANEB);
+      for (int q = 0; q < P; ++q) Aq1[q] = *(const bf16x8*)(vb + pos_of(0) * POSB + q * PLANEB);
+#define AQ(q) Aq1[q]
+#endif
 #pragma unroll
       for (int pi = 0; pi < 8; ++pi) {
         const int p0 = pos_of(pi);
         const bool live = !ZSKIP || !is_zero(pi);  // wave-uniform
-        if (live && !(a.dbg & 16)) {
+#if WB_ADOUBLE
+        if (pi + 1 < 8) {
+#pragma unroll
+          for (int q = 0; q < P; ++q) Aq[(pi + 1) & 1][q] = *(const bf16x8*)(vb + pos_of(pi + 1) * POSB + q * PLANEB);
+        }
+#endif
+        if (live && !(WB_ABL & 16)) {
           const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           floatx16 c = FIRST ? zero : acc[p0];
           if (P == 3) {  // small terms first
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[0], Bq[pi % RING][P - 1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[P - 1], Bq[pi % RING][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[1], Bq[pi % RING][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AQ(0), Bq[pi % RING][P - 1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AQ(P - 1), Bq[pi % RING][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AQ(1), Bq[pi % RING][1], c, 0, 0, 0);
           }
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[0], Bq[pi % RING][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[1], Bq[pi % RING][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[0], Bq[pi % RING][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AQ(0), Bq[pi % RING][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AQ(1), Bq[pi % RING][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AQ(0), Bq[pi % RING][0], c, 0, 0, 0);
           acc[p0] = c;
         } else if (FIRST) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[p0][e] = 0.f;
         }
+#if !WB_ADOUBLE
         if (pi + 1 < 8) {
 #pragma unroll
-          for (int q = 0; q < P; ++q) Aq[q] = *(const bf16x8*)(vb + pos_of(pi + 1) * POSB + q * PLANEB);
+          for (int q = 0; q < P; ++q) Aq1[q] = *(const bf16x8*)(vb + pos_of(pi + 1) * POSB + q * PLANEB);
         }
+#endif
         {
           // refill this ring slot with the fragments of step pi + RING (next chunk / next tile past 7)
           const int f = pi + RING;
@@ -505,11 +563,11 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
                                     : (last ? soff_of(soff_phase_nxt, 0, f - 8) : soff_of(soff_phase, chunk + 1, f - 8));
           // a structurally zero position of THIS chunk is never multiplied: its fragments are not
           // fetched at all (the vector-memory path, 64 B/clk per CU, is what bounds this kernel).
-          // Steps of the next chunk / tile (f >= 8) start at a position that is never zero for
-          // f - 8 < RING only in MODE 1; they are fetched unconditionally.
+          // Steps of the next chunk / tile (f >= 8) are fetched unconditionally.
           if (!(ZSKIP && f < 8 && is_zero(f))) fetch(Bq[pi % RING], so);
         }
       }
+#undef AQ
       WSTAMP(0, 3 * chunk + 1);
       __syncthreads();  // B_chunk
       WSTAMP(0, 3 * chunk + 2);
@@ -520,7 +578,7 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
 
     // ---- inverse transform (as conv_wino.hip) -----------------------------------------------
     WSTAMP(0, 60);
-    if (a.dbg & 8) {
+    if (WB_ABL & 8) {
       __syncthreads();
     } else {
       float* yown = yreg + ((4 * (2 * ph) + nt) * 32 + 4 * h) * WP + l31;
@@ -663,10 +721,6 @@ static int wb_launch(wb::Args& a, hipStream_t st) {
       return DSIC_EHIP;
     }
     attr_set[dev] = true;
-  }
-  {
-    const char* d = getenv("DSIC_WB_DBG");
-    a.dbg = d ? atoi(d) : 0;
   }
   static int max_grid = 0;
   if (max_grid == 0) {

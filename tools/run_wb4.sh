@@ -3,7 +3,7 @@ rm -rf $OUT && mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 timeout -k 10 300 python3 -m pytest tests/test_gpu_conv.py tests/test_gpu_model.py -m gpu -q -x > $OUT/pytest.log 2>&1
 echo "tests rc=$?"; tail -5 $OUT/pytest.log
-for L in 3x3 s2 convT; do for D in 0 2; do echo -n "LAYER=$L DBG=$D  "; LAYER=$L DSIC_WB_DBG=$D python3 tools/wb_layer.py 2>/dev/null | tail -1; done; done
+for L in 3x3 s2 convT; do echo -n "LAYER=$L  "; LAYER=$L python3 tools/wb_layer.py 2>/dev/null | tail -1; done
 for rep in 1 2; do
 python3 bench.py --no-entropy --no-cpu-baseline --kernels > $OUT/c2.json 2> $OUT/c2.err
 python3 bench.py --no-cpu-baseline --kernels > $OUT/c3.json 2> $OUT/c3.err
