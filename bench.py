@@ -135,6 +135,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernels", action="store_true", help="also print the per-kernel event timings to stderr")
     ap.add_argument("--streams-per-wg", type=int, default=4, help="range-coder waves per workgroup (1..16)")
+    ap.add_argument("--coder-depth", type=int, default=2,
+                    help="batches whose strings may be in the coder at once (side streams, round-robin); the coded "
+                         "size of batch i enters the metric reduction of step i + depth")
     ap.add_argument("--coder-cus", type=int, default=0,
                     help="CUs reserved for the range coder's stream (0 = no CU masking)")
     ap.add_argument("--no-entropy", action="store_true",
@@ -178,7 +181,7 @@ def main():
             main_stream, side = entropy.masked_streams(args.coder_cus)
             coder = entropy.AsyncCompressor(model, stream=side, streams_per_wg=8)
         else:
-            coder = entropy.AsyncCompressor(model, streams_per_wg=args.streams_per_wg)
+            coder = entropy.AsyncCompressor(model, streams_per_wg=args.streams_per_wg, depth=args.coder_depth)
         coder.timing = True
     torch.cuda.set_stream(main_stream)
     count = torch.tensor(float(B), dtype=torch.float64, device=dev)
@@ -193,12 +196,13 @@ def main():
         msssim = metrics.ms_ssim_per_image(out["x_hat"], x, clamp_x=True)
         real = zero
         if coder is not None:
-            # the strings of THIS step are still being coded beside synthesis; the coded size
-            # that enters this step's reduction is the previous step's (same batch), joined at
-            # stream level without a host sync.  The last step is joined before the clock stops.
-            prev = pending.pop() if pending else None
+            # the strings of THIS step are still being coded beside synthesis (and the next steps'
+            # analysis); the coded size that enters this step's reduction is that of the step
+            # `coder_depth` earlier (same batch), joined at stream level without a host sync.  The
+            # last steps are joined before the clock stops.
             pending.append(coder.last)
-            if prev is not None:
+            if len(pending) > max(1, args.coder_depth):
+                prev = pending.pop(0)
                 torch.cuda.current_stream().wait_event(prev["done"])
                 real = prev["lengths"].sum().double() * 8.0 / float(H * W)   # eval_selfcontained_entropy.py:148-149
         t = torch.stack([bpp.sum(), msssim.double().sum(), count, real])

@@ -134,17 +134,40 @@ __device__ __forceinline__ void put_ones(uint32_t* out32, int64_t cap_bits, int6
 // renormalisation — are recorded: which bits became final (E1/E2), how long the E3 run is and
 // what is owed from earlier symbols is recomputed from them by the 64 lanes in parallel.
 // ~22 scalar instructions per symbol instead of ~55.
+#ifndef ENC_SELECT
+#define ENC_SELECT 1   // 1: s_cselect for the span = 2^32 case (4 % faster than a branch per symbol)
+#endif
 template <int J>
 __device__ __forceinline__ void wlane(uint32_t& rec, uint32_t v) {
   asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(rec) : "s"(v), "n"(J));
 }
 
 template <int J>
-__device__ __forceinline__ void enc_step(uint32_t& low, uint32_t& span, uint32_t clo16, uint32_t chi16,
-                                         uint32_t& rec_low, uint32_t& rec_high) {
-  const uint32_t cl = __builtin_amdgcn_readlane(clo16, J);
-  const uint32_t ch = __builtin_amdgcn_readlane(chi16, J);
+__device__ __forceinline__ uint32_t rlane(uint32_t v) {
+  uint32_t r;
+  asm volatile("v_readlane_b32 %0, %1, %2" : "=s"(r) : "v"(v), "n"(J));
+  return r;
+}
+
+// (cl, ch): the bounds of symbol J, read one step earlier; the step first reads those of symbol J+1,
+// so the VALU -> SGPR latency of v_readlane never sits on the serial chain.
+template <int J>
+__device__ __forceinline__ void enc_step(uint32_t& low, uint32_t& lowm1, uint32_t& span, uint32_t& cl,
+                                         uint32_t& ch, uint32_t clo16, uint32_t chi16, uint32_t& rec_low,
+                                         uint32_t& rec_high) {
+  // The chain span -> span of the next symbol is ~9 dependent scalar operations (mul_hi, select,
+  // sub/add, xor | orn2, flbit | shift, shift, flbit, add, shift); low - 1 and the record stores sit
+  // beside it.
+  const uint32_t cl_next = J < 63 ? rlane<(J < 63 ? J + 1 : 63)>(clo16) : 0u;
+  const uint32_t ch_next = J < 63 ? rlane<(J < 63 ? J + 1 : 63)>(chi16) : 0u;
   uint32_t lo_add, hi_add;
+#if ENC_SELECT
+  {  // branch-free: span = 2^32 (kept as 0) selects (2^32 c) >> 16 = c << 16
+    const uint32_t ml = __umulhi(span, cl), mh = __umulhi(span, ch);
+    lo_add = span ? ml : cl;
+    hi_add = span ? mh : ch;
+  }
+#else
   if (__builtin_expect(span == 0u, 0)) {  // span = 2^32: (2^32 c) >> 16
     lo_add = cl;
     hi_add = ch;
@@ -152,30 +175,35 @@ __device__ __forceinline__ void enc_step(uint32_t& low, uint32_t& span, uint32_t
     lo_add = __umulhi(span, cl);
     hi_add = __umulhi(span, ch);
   }
+#endif
   const uint32_t low1 = low + lo_add;
+  const uint32_t high1 = lowm1 + hi_add;         // low - 1 + floor(span c_high / 2^16)
   const uint32_t span1 = hi_add - lo_add;        // >= 2^14 - 1
-  const uint32_t high1 = low1 + span1 - 1u;
   wlane<J>(rec_low, low1);
   wlane<J>(rec_high, high1);
   const int nb = __builtin_clz(low1 ^ high1);    // E1/E2
-  const uint32_t q = high1 | ~low1;              // 0 where (low, high) = (1, 0): E3 pairs below the split bit
-  const int m = __builtin_clz((q << nb) << 1);   // != 0: an all-E3 tail would need span1 == 2
+  const uint32_t q2 = (high1 | ~low1) << 1;      // 0 where (low, high) = (1, 0): E3 pairs below the split bit
+  const int m = __builtin_clz(q2 << nb);         // != 0: an all-E3 tail would need span1 == 2
   const int sh = nb + m;
-  low = (low1 << sh) & 0x7FFFFFFFu;
   span = span1 << sh;                            // exactly 2^32 -> 0
+  low = (low1 << sh) & 0x7FFFFFFFu;
+  lowm1 = low - 1u;
+  cl = cl_next;
+  ch = ch_next;
 }
 
 template <int J0>
-__device__ __forceinline__ void enc_steps8(uint32_t& low, uint32_t& span, uint32_t clo16, uint32_t chi16,
-                                           uint32_t& rec_low, uint32_t& rec_high) {
-  enc_step<J0 + 0>(low, span, clo16, chi16, rec_low, rec_high);
-  enc_step<J0 + 1>(low, span, clo16, chi16, rec_low, rec_high);
-  enc_step<J0 + 2>(low, span, clo16, chi16, rec_low, rec_high);
-  enc_step<J0 + 3>(low, span, clo16, chi16, rec_low, rec_high);
-  enc_step<J0 + 4>(low, span, clo16, chi16, rec_low, rec_high);
-  enc_step<J0 + 5>(low, span, clo16, chi16, rec_low, rec_high);
-  enc_step<J0 + 6>(low, span, clo16, chi16, rec_low, rec_high);
-  enc_step<J0 + 7>(low, span, clo16, chi16, rec_low, rec_high);
+__device__ __forceinline__ void enc_steps8(uint32_t& low, uint32_t& lowm1, uint32_t& span, uint32_t& cl,
+                                           uint32_t& ch, uint32_t clo16, uint32_t chi16, uint32_t& rec_low,
+                                           uint32_t& rec_high) {
+  enc_step<J0 + 0>(low, lowm1, span, cl, ch, clo16, chi16, rec_low, rec_high);
+  enc_step<J0 + 1>(low, lowm1, span, cl, ch, clo16, chi16, rec_low, rec_high);
+  enc_step<J0 + 2>(low, lowm1, span, cl, ch, clo16, chi16, rec_low, rec_high);
+  enc_step<J0 + 3>(low, lowm1, span, cl, ch, clo16, chi16, rec_low, rec_high);
+  enc_step<J0 + 4>(low, lowm1, span, cl, ch, clo16, chi16, rec_low, rec_high);
+  enc_step<J0 + 5>(low, lowm1, span, cl, ch, clo16, chi16, rec_low, rec_high);
+  enc_step<J0 + 6>(low, lowm1, span, cl, ch, clo16, chi16, rec_low, rec_high);
+  enc_step<J0 + 7>(low, lowm1, span, cl, ch, clo16, chi16, rec_low, rec_high);
 }
 
 __global__ __launch_bounds__(1024) void range_encode_kernel(
@@ -241,16 +269,17 @@ __global__ __launch_bounds__(1024) void range_encode_kernel(
     if (cnt == 64 && !__any(c_hi_v == 0x10000u)) {
       // ---- fast path ----
       uint32_t rec_low = 0, rec_high = 0;
-      uint32_t span = high - low + 1u;
+      uint32_t span = high - low + 1u, lowm1 = low - 1u;
       const uint32_t clo16 = c_lo_v << 16, chi16 = c_hi_v << 16;
-      enc_steps8<0>(low, span, clo16, chi16, rec_low, rec_high);
-      enc_steps8<8>(low, span, clo16, chi16, rec_low, rec_high);
-      enc_steps8<16>(low, span, clo16, chi16, rec_low, rec_high);
-      enc_steps8<24>(low, span, clo16, chi16, rec_low, rec_high);
-      enc_steps8<32>(low, span, clo16, chi16, rec_low, rec_high);
-      enc_steps8<40>(low, span, clo16, chi16, rec_low, rec_high);
-      enc_steps8<48>(low, span, clo16, chi16, rec_low, rec_high);
-      enc_steps8<56>(low, span, clo16, chi16, rec_low, rec_high);
+      uint32_t cl = rlane<0>(clo16), ch = rlane<0>(chi16);
+      enc_steps8<0>(low, lowm1, span, cl, ch, clo16, chi16, rec_low, rec_high);
+      enc_steps8<8>(low, lowm1, span, cl, ch, clo16, chi16, rec_low, rec_high);
+      enc_steps8<16>(low, lowm1, span, cl, ch, clo16, chi16, rec_low, rec_high);
+      enc_steps8<24>(low, lowm1, span, cl, ch, clo16, chi16, rec_low, rec_high);
+      enc_steps8<32>(low, lowm1, span, cl, ch, clo16, chi16, rec_low, rec_high);
+      enc_steps8<40>(low, lowm1, span, cl, ch, clo16, chi16, rec_low, rec_high);
+      enc_steps8<48>(low, lowm1, span, cl, ch, clo16, chi16, rec_low, rec_high);
+      enc_steps8<56>(low, lowm1, span, cl, ch, clo16, chi16, rec_low, rec_high);
       high = low + span - 1u;
       // lanes: what symbol j emitted
       nbv = (uint32_t)__builtin_clz(rec_low ^ rec_high);

@@ -157,14 +157,21 @@ def masked_streams(coder_cus=16, total_cus=256, xcds=8):
 
 
 class AsyncCompressor:
-    """Runs compress_latents on a side HIP stream so that the serial range coder
-    overlaps synthesis (and the next batch's analysis).  Use as the `after_rate`
-    hook of CompressionModel.forward; call .wait() before reading `.last`."""
+    """Runs compress_latents on side HIP streams so that the serial range coder overlaps
+    synthesis (and the following batches' analysis).  Use as the `after_rate` hook of
+    CompressionModel.forward; call .wait() before reading `.last`.
 
-    def __init__(self, model, tail=10, Lmax=DEFAULT_LMAX, stream=None, streams_per_wg=4):
+    `depth` side streams are used round-robin: the coder of batch i+1 does not queue behind the
+    coder of batch i, so a coder that takes longer than one step (512x512 patches: 196 608 y symbols
+    per string, a serial chain) still keeps up - its latency is hidden, its throughput doubles."""
+
+    def __init__(self, model, tail=10, Lmax=DEFAULT_LMAX, stream=None, streams_per_wg=4, depth=1):
         self.model, self.tail, self.Lmax = model, tail, Lmax
         self.streams_per_wg = streams_per_wg
-        self.stream = stream if stream is not None else torch.cuda.Stream()
+        self.streams = [stream if stream is not None else torch.cuda.Stream()]
+        self.streams += [torch.cuda.Stream() for _ in range(max(1, int(depth)) - 1)]
+        self.stream = self.streams[0]
+        self.calls = 0
         self.last = None
         self._sigma_z = None
         self.timing = False          # bench.py: keep a HIP-event pair per call on the coder's stream
@@ -188,32 +195,36 @@ class AsyncCompressor:
 
     def __call__(self, partial):
         main = torch.cuda.current_stream()
+        side = self.streams[self.calls % len(self.streams)]
+        self.calls += 1
         if self._sigma_z is None:
             self._sigma_z = sigma_z_of(self.model)
-            self._sigma_z.record_stream(self.stream)
+            for st in self.streams:
+                self._sigma_z.record_stream(st)
         if self._ready is None:
             self._ready = torch.cuda.Event()
         ready = self._ready              # re-recorded per call; wait_event captures this record
         ready.record(main)
         tensors = [partial["y_tilde"], partial["z_tilde"], partial["sigma"], partial["nu"]]
-        with torch.cuda.stream(self.stream):
-            self.stream.wait_event(ready)
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
             for t in tensors:
-                t.record_stream(self.stream)      # allocator must not recycle them under the coder
+                t.record_stream(side)             # allocator must not recycle them under the coder
             if self.timing:
                 e0, done = self._pair()
-                e0.record(self.stream)
+                e0.record(side)
             else:
                 done = torch.cuda.Event()
             self.last = compress_latents(tensors[0], tensors[1], tensors[2], tensors[3], self._sigma_z,
                                          self.tail, self.Lmax, self.streams_per_wg)
-            done.record(self.stream)
+            done.record(side)
             if self.timing:
                 self.times.append((e0, done))
             self.last["done"] = done
 
     def wait(self):
-        torch.cuda.current_stream().wait_stream(self.stream)
+        for st in self.streams:
+            torch.cuda.current_stream().wait_stream(st)
         return self.last
 
 

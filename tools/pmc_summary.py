@@ -21,6 +21,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "round1"
+commit = sys.argv[2] if len(sys.argv) > 2 else "unknown"
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
@@ -32,9 +33,10 @@ def short(name):
         args = [a.strip() for a in m.group(1).split(",")]
         args = ["1" if a == "true" else "0" if a == "false" else a for a in args]
         return "conv_igemm_kernel<" + ",".join(args) + ">"
-    m = re.search(r"(conv_wino_kernel|conv_first_kernel)<([^>]*)>", name)
+    m = re.search(r"(conv_wino_bf16_kernel|conv_wino_kernel|conv_first_kernel)<([^>]*)>", name)
     if m:
-        arg = {"true": "1", "false": "0"}.get(m.group(2).strip(), m.group(2).strip())
+        arg = m.group(2).split(",")[0].strip()          # conv_first_kernel<3, false> -> <3>
+        arg = {"true": "1", "false": "0"}.get(arg, arg)
         return f"{m.group(1)}<{arg}>"
     return re.sub(r"\(.*", "", name).replace("void ", "").replace("dsic::", "")
 
@@ -56,7 +58,7 @@ write = agg(os.path.join(G, "p3", "write_counter_collection.csv"), "WRITE_SIZE")
 out = {}
 detail = {}
 for k in sorted(set(fetch) | set(write)):
-    if not (k.startswith("conv_") or k.startswith("convT_") or k in ("rate_kernel", "ssim_level_kernel", "range_encode_kernel",
+    if not (k.startswith("conv_") or k.startswith("convT_") or k in ("rate_kernel", "ssim_level_kernel", "range_encode_kernel", "tables_kernel",
                                                   "hyper_params_kernel", "image_to_nhwc8_kernel")):
         continue
     fn, fv = fetch.get(k, [0, 0.0])
@@ -65,6 +67,7 @@ for k in sorted(set(fetch) | set(write)):
     wb = wv / max(wn, 1) * 1024.0
     out[k] = fb + wb
     detail[k] = {"launches_sampled": fn, "fetch_bytes_per_launch_corrected": fb, "write_bytes_per_launch": wb}
+out["_commit"] = commit
 json.dump(out, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
 json.dump(detail, open(os.path.join(P, f"{tag}_pmc_detail.json"), "w"), indent=1)
 for src, dst in (("p1_bench.log", f"{tag}_bench_under_rocprof.log"),):
@@ -92,3 +95,5 @@ if os.path.exists(p5):
                    "mfma_flop_per_launch": v.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) * 512.0 / launches[k]}
     json.dump(util, open(os.path.join(P, f"{tag}_mfma_util.json"), "w"), indent=1)
     print(json.dumps({k: round(v["mfma_util"], 3) for k, v in util.items()}, indent=1))
+    util["_commit"] = commit
+    json.dump(util, open(os.path.join(P, "mfma_util.json"), "w"), indent=1)
