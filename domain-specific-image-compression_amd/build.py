@@ -47,6 +47,11 @@ def _compile(src, obj):
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
+    # objects built with other flags (A/B and diagnostic builds set DSIC_EXTRA_FLAGS) are stale
+    flag_file = os.path.join(OBJ, ".flags")
+    flag_str = " ".join(FLAGS)
+    if not os.path.exists(flag_file) or open(flag_file).read() != flag_str:
+        force = True
     hdr_m = _deps_mtime()
     jobs, objs = [], []
     for src in _sources():
@@ -64,6 +69,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    with open(flag_file, "w") as f:
+        f.write(flag_str)
     return LIB
 
 

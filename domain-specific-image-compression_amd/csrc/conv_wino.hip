@@ -763,7 +763,10 @@ static int wino_launch(WinoArgs& a, hipStream_t st) {
   // Small outputs are read back by the next layer from L2/MALL (cached stores measured 1-3 % faster per
   // step); an output that cannot stay there anyway is streamed (1 % faster per layer).
   a.nt_out = (int64_t)B * H * W * a.Cout * 4 * (a.nphase == 4 ? 4 : 1) > WINO_NT_BYTES;
-  static bool attr_set = false;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  static bool attr_set_dev[64] = {};
+  bool& attr_set = attr_set_dev[dev];  // per device: the attribute belongs to the device's code object
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv_wino_kernel<0>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, WLDS_TOTAL);

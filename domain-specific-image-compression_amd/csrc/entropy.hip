@@ -27,13 +27,16 @@ __global__ __launch_bounds__(256) void support_kernel(const float* __restrict__ 
                                                       int* __restrict__ meta, int64_t ny, int64_t nz,
                                                       int tail) {
   __shared__ float red[2][4];
+  __shared__ int bad_any;
   const int b = blockIdx.x;
   for (int which = 0; which < 2; ++which) {
     const float* p = which ? z + (size_t)b * nz : y + (size_t)b * ny;
     const int64_t n = which ? nz : ny;
     float mn = p[0], mx = p[0];
+    bool bad = false;  // NaN, infinity or a magnitude no int support can hold
     for (int64_t i = threadIdx.x; i < n; i += 256) {
       const float v = p[i];
+      bad |= !(fabsf(v) < 1.0e9f);
       mn = fminf(mn, v);
       mx = fmaxf(mx, v);
     }
@@ -42,19 +45,28 @@ __global__ __launch_bounds__(256) void support_kernel(const float* __restrict__ 
       mn = fminf(mn, __shfl_down(mn, o, 64));
       mx = fmaxf(mx, __shfl_down(mx, o, 64));
     }
+    if (threadIdx.x == 0) bad_any = 0;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) {
       red[0][threadIdx.x >> 6] = mn;
       red[1][threadIdx.x >> 6] = mx;
     }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&bad_any, 1);
     __syncthreads();
     if (threadIdx.x == 0) {
       mn = fminf(fminf(red[0][0], red[0][1]), fminf(red[0][2], red[0][3]));
       mx = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
-      const int lo = (int)floorf(mn) - tail, hi = (int)ceilf(mx) + tail;
-      meta[4 * b + 2 * which] = lo;
-      meta[4 * b + 2 * which + 1] = hi - lo + 1;
+      if (bad_any) {
+        // non-finite latents have no support: width 0 makes every consumer of `meta` raise err bit 1
+        meta[4 * b + 2 * which] = 0;
+        meta[4 * b + 2 * which + 1] = 0;
+      } else {
+        const int lo = (int)floorf(mn) - tail, hi = (int)ceilf(mx) + tail;
+        meta[4 * b + 2 * which] = lo;
+        meta[4 * b + 2 * which + 1] = hi - lo + 1;
+      }
     }
+    __syncthreads();
   }
 }
 

@@ -88,8 +88,9 @@ def cdf_tables(sigma_y, nu_y, sigma_z, meta, Lmax=DEFAULT_LMAX, err=None):
     dev = sy.device
     if err is None:
         err = torch.zeros(1, dtype=torch.int32, device=dev)
-    tab_y = torch.zeros((B, M, Lmax), dtype=torch.uint16, device=dev)
-    tab_z = torch.zeros((B, N, Lmax), dtype=torch.uint16, device=dev)
+    # entries k >= L_b of a row are never read (every reader stops at the support width in `meta`)
+    tab_y = torch.empty((B, M, Lmax), dtype=torch.uint16, device=dev)
+    tab_z = torch.empty((B, N, Lmax), dtype=torch.uint16, device=dev)
     L = _lib.load()
     _lib.check(L.dsic_cdf_tables_gauss(_p(sz), _p(meta), _p(tab_z), B, N, Lmax, _p(err), _stream()),
                "cdf_tables_gauss")
@@ -120,7 +121,8 @@ def compress_latents(y_tilde, z_tilde, sigma_y, nu_y, sigma_z, tail=10, Lmax=DEF
     meta = latent_support(y, z, tail)
     tab_y, tab_z, err = cdf_tables(sigma_y, nu_y, sigma_z, meta, Lmax)
     cap_y, cap_z = _cap(M * Hy * Wy), _cap(N * Hz * Wz)
-    out = torch.zeros((B, cap_z + cap_y), dtype=torch.uint8, device=dev)   # the coder ORs its bits in
+    # the coder ORs its bits in: zero-filled, as 32-bit words (a byte fill kernel takes 4x the elements)
+    out = torch.zeros((B, (cap_z + cap_y) // 4), dtype=torch.int32, device=dev).view(torch.uint8)
     lengths = torch.zeros((B, 2), dtype=torch.int32, device=dev)
     _lib.check(_lib.load().dsic_range_encode(_p(y), _p(z), _p(meta), _p(tab_y), _p(tab_z), Lmax, B, M, Hy * Wy,
                                              N, Hz * Wz, _p(out), cap_y, cap_z, _p(lengths), _p(err),

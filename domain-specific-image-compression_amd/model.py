@@ -115,7 +115,9 @@ def rate_distortion_loss(out, x, lambda_rd=10000.0, dist="mssim"):
         D = metrics.mse(x_hat, x)
     else:
         if x_hat.shape[2:] != x.shape[2:]:
-            raise ValueError("msssim: x_hat and x must have the same size (crop or pad first)")
+            # model.py:95-96: the reference resizes x_hat bilinearly when the sizes differ (never the case
+            # for inputs padded to a multiple of 16); rare path, plain torch on the device tensors
+            x_hat = torch.nn.functional.interpolate(x_hat, size=x.shape[2:], mode="bilinear", align_corners=False)
         D = 1.0 - metrics.ms_ssim(x_hat.clamp(0, 1), x, data_range=1.0, weights=(0.3, 0.5, 0.2))
     loss = lambda_rd * D + R
     return loss, R, D

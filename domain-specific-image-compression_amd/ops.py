@@ -18,6 +18,8 @@ def _p(t):
 
 
 def _stream():
+    # one process drives one GPU (torch.distributed, one rank per device): the current stream of the
+    # current device.  Tensors on another device are rejected by _f32c's callers' pointer checks.
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -235,3 +235,18 @@ def test_spatial_params_model_and_entropy_path():
         assert got["strings"][b][1] == want["strings"][b][1]
         assert np.array_equal(E.decode_y(got, b, sy[b], ny[b]), y[b])
     assert torch.equal(entropy.custom_decompress(m, got), out["x_hat"].clamp(0, 1))
+
+
+def test_non_finite_latents_are_reported():
+    """A NaN / infinite latent has no integer support (the reference would raise inside int(floor(.)),
+    eval_selfcontained_entropy.py:39): the support scan reports width 0 and every later stage flags it."""
+    from dsic_amd import entropy
+    for bad in (float("nan"), float("inf"), -float("inf")):
+        y = torch.zeros((2, 4, 2, 2), device="cuda"); y[1, 2, 0, 1] = bad
+        z = torch.zeros((2, 2, 1, 1), device="cuda")
+        c = entropy.compress_latents(y, z, torch.ones((2, 4), device="cuda"), torch.full((2, 4), 3.0, device="cuda"),
+                                     torch.ones(2, device="cuda"), tail=10, Lmax=64)
+        m = c["meta"].cpu().numpy()
+        assert m[1, 1] == 0 and m[0, 1] == 21
+        with pytest.raises(entropy.EntropyError):
+            entropy._check_err(c["err"], "test")

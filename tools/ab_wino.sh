@@ -2,6 +2,8 @@
 # A/B builds of conv_wino.hip on the same box (diagnostic): one argument per build = its extra flags.
 set -e
 cd "$(dirname "$0")/.."
+# leave the default library behind, whatever happens (build.py also rebuilds when the flag string changes)
+trap 'DSIC_EXTRA_FLAGS= python domain-specific-image-compression_amd/build.py > /dev/null 2>&1' EXIT
 for v in "$@"; do
   touch domain-specific-image-compression_amd/csrc/conv_wino.hip
   DSIC_EXTRA_FLAGS="$v" python domain-specific-image-compression_amd/build.py > /dev/null 2>&1
