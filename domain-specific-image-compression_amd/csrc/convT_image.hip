@@ -15,11 +15,29 @@
 // D[i=4q+v][j=r]; k-step s of a chunk pairs channels {4q+s}, so both operands are one 16-byte read
 // per lane for four MFMAs.  Weights are packed [tap][Cin/16][col 16][16 ch] (73.7 KB for Cin=128,
 // L1/L2 resident).  Epilogue: + bias, interleave the phases through LDS, 16-byte NCHW stores.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dsic {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef short shortx4 __attribute__((ext_vector_type(4)));
+typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
+
+// fp32 quad -> two bf16 planes (hi = bf16(v), mid = bf16(v - hi)), each 4 bf16 = 8 bytes.  The conversions
+// are compiler builtins, not inline asm: their results feed MFMA operands directly, and only for
+// instructions it knows does the compiler insert the wait states a VALU write needs before an MFMA read.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void img_split(floatx4 v, uintx2& hi, uintx2& mid) {
+  hi = __builtin_bit_cast(uintx2, __builtin_convertvector(v, bf16x4));
+  floatx4 r;
+  r[0] = v[0] - __builtin_bit_cast(float, hi[0] << 16);
+  r[1] = v[1] - __builtin_bit_cast(float, hi[0] & 0xFFFF0000u);
+  r[2] = v[2] - __builtin_bit_cast(float, hi[1] << 16);
+  r[3] = v[3] - __builtin_bit_cast(float, hi[1] & 0xFFFF0000u);
+  mid = __builtin_bit_cast(uintx2, __builtin_convertvector(r, bf16x4));
+}
 
 constexpr int IT_W = 32, IT_H = 16;          // input-grid pixels per workgroup tile
 constexpr int IW = IT_W + 2, IH = IT_H + 2;  // staged window
@@ -38,6 +56,12 @@ struct ImgArgs {
 #ifndef IMG_WGS
 #define IMG_WGS 2  // workgroups per CU the register budget is set for (3 spills and is slower)
 #endif
+// BF16 = true: the contraction runs on v_mfma_f32_16x16x16_bf16 with both operands split into two
+// bf16 planes (products hi*hi, hi*mid, mid*hi, fp32 accumulate - the scheme of conv_wino_bf16.hip):
+// three bf16 MFMAs replace four fp32-input ones at a quarter of their cycles each.  The window is
+// split once while it is staged (LDS pixel record: 16 bf16 hi | 16 bf16 mid | pad = the same 80
+// bytes as 16 fp32 + pad), the weight quads when they are fetched.
+template <bool BF16>
 __global__ __launch_bounds__(256, IMG_WGS) void convT_image_kernel(const ImgArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[IH * IW * IP];  // 48 960 B; reused as the output tile
   const int tid = threadIdx.x, lane = tid & 63;
@@ -79,7 +103,19 @@ __global__ __launch_bounds__(256, IMG_WGS) void convT_image_kernel(const ImgArgs
   auto store_chunk = [&]() {
 #pragma unroll
     for (int i = 0; i < ISLOTS; ++i)
-      if (loff[i] >= 0) *(floatx4*)(lds + loff[i]) = stage[i];
+      if (loff[i] >= 0) {
+        if (BF16) {
+          // pixel record: hi quads at +0..31, mid quads at +32..63 (bytes); loff = pix*IP + cq*4 floats
+          uintx2 hi, mid;
+          img_split(stage[i], hi, mid);
+          unsigned char* rec = (unsigned char*)lds + (size_t)(loff[i] / IP) * (IP * 4);
+          const int cq = (loff[i] % IP) >> 2;
+          *(uintx2*)(rec + cq * 8) = hi;
+          *(uintx2*)(rec + 32 + cq * 8) = mid;
+        } else {
+          *(floatx4*)(lds + loff[i]) = stage[i];
+        }
+      }
   };
 
   floatx4 acc[8];
@@ -101,11 +137,27 @@ __global__ __launch_bounds__(256, IMG_WGS) void convT_image_kernel(const ImgArgs
       const int wr = tap / 3, wc = tap % 3;
       const floatx4 bc = b;
       if (tap + 1 < 9) b = *(const floatx4*)(wl + (size_t)((tap + 1) * C16 + chunk) * 256);
+      if (BF16) {
+        uintx2 bh, bm;
+        img_split(bc, bh, bm);
+        const shortx4 Bh = __builtin_bit_cast(shortx4, bh), Bm = __builtin_bit_cast(shortx4, bm);
+        // A fragment of lane (r, q): channels 4q..4q+3 of pixel r: 8 bytes of the hi part, 8 of the mid part
+        const unsigned char* abyte = (const unsigned char*)lds + (size_t)((wave * 4) * IW + r) * (IP * 4) + q * 8;
 #pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const floatx4 av = *(const floatx4*)(lds + abase + (((m >> 1) + wr) * IW + (m & 1) * 16 + wc) * IP);
+        for (int m = 0; m < 8; ++m) {
+          const unsigned char* ap = abyte + (size_t)((((m >> 1) + wr) * IW + (m & 1) * 16 + wc) * (IP * 4));
+          const shortx4 Ah = *(const shortx4*)ap, Am = *(const shortx4*)(ap + 32);
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Ah, Bm, acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Am, Bh, acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Ah, Bh, acc[m], 0, 0, 0);
+        }
+      } else {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bc[s], acc[m], 0, 0, 0);
+        for (int m = 0; m < 8; ++m) {
+          const floatx4 av = *(const floatx4*)(lds + abase + (((m >> 1) + wr) * IW + (m & 1) * 16 + wc) * IP);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bc[s], acc[m], 0, 0, 0);
+        }
       }
     }
   }
@@ -201,6 +253,16 @@ extern "C" int dsic_conv_transpose2d_image(const float* in, const float* w_packe
   a.tiles_x = ceil_div(W, IT_W); a.tiles_y = ceil_div(H, IT_H);
   const int64_t nblk = (int64_t)a.tiles_x * a.tiles_y * B;
   DSIC_REQUIRE(nblk < ((int64_t)1 << 31), "convT_image: grid too large");
-  hipLaunchKernelGGL(convT_image_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, a);
+  // DSIC_WINO_BF16=0 (the switch of the split-bf16 contractions, see conv_wino_bf16.hip) keeps this layer on
+  // the fp32-input MFMA as well
+  static int use_bf16 = -1;
+  if (use_bf16 < 0) {
+    const char* e = getenv("DSIC_WINO_BF16");
+    use_bf16 = (e && e[0] == '0' && e[1] == 0) ? 0 : 1;
+  }
+  if (use_bf16)
+    hipLaunchKernelGGL(convT_image_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(convT_image_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("convT_image");
 }

@@ -74,6 +74,9 @@ def test_units_against_reference_fixtures(ops):
             y = ops.nhwc_to_nchw(ops.conv_transpose2d_nhwc(_nhwc(x), ops.pack_convT_weight(w), b, cout))
         else:
             y = ops.conv_transpose2d_image(_nhwc(x), ops.pack_convT_image_weight(w), b, cout)
+            # the image layer runs on split-bf16 MFMAs (2 planes) unless DSIC_WINO_BF16=0: 4x the fp32 class
+            np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), atol=_tol(ref, 200) * 4)
+            continue
         np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), atol=_tol(ref, 200))
 
 
@@ -156,7 +159,10 @@ def test_conv_transpose_image_vs_oracle(ops, B, Cin, Cimg, H, W):
     got = ops.conv_transpose2d_image(_nhwc(x).cuda(), ops.pack_convT_image_weight(w.cuda()), b.cuda(), Cimg).cpu()
     assert got.shape == ref.shape
     err = float((got - ref).abs().max())
-    assert err <= _tol(ref, Cin * 9) * 4, (err, float(ref.abs().max()))
+    print(f"image layer err/|ref|max = {err / float(ref.abs().max()):.2e}")
+    # split-bf16 contraction (2 planes, 3 products) unless DSIC_WINO_BF16=0: dropped cross terms 2^-16 per product
+    import os
+    assert err <= _tol(ref, Cin * 9) * (4 if os.environ.get("DSIC_WINO_BF16") == "0" else 16), (err, float(ref.abs().max()))
 
 
 def test_bad_arguments_raise(ops):
