@@ -78,6 +78,7 @@ struct Args {
   int s2d_in, s2d;
   int tiles_x, tiles_y, ntiles;
   int nt_out;
+  int ostride, ooff;  // output pixel stride and channel offset in floats (a Cout slice of a wider tensor)
 };
 
 constexpr int P = WB_PLANES;
@@ -309,16 +310,16 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
       const int phase = t.item & (a.nphase - 1);
       const int ppy = phase >> 1, ppx = phase & 1;
       const int OH = a.nphase == 4 ? 2 * a.H : a.H, OW = a.nphase == 4 ? 2 * a.W : a.W;
-      o.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)t.n * OH * OW * a.Cout), 0,
-                                               OH * OW * a.Cout * 4, 0x00020000);
+      o.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)t.n * OH * OW * a.ostride + a.ooff), 0,
+                                               (OH * OW * a.ostride - a.ooff) * 4, 0x00020000);
 #pragma unroll
       for (int ij = 0; ij < 4; ++ij) {
         const int oy = t.ty * 8 + 2 * oty + (ij >> 1);
         const int ox = t.tx * 16 + 2 * otx + (ij & 1);
         const unsigned po =
-            (unsigned)(a.nphase == 4 ? ((2 * oy + ppy) * OW + (2 * ox + ppx)) * a.Cout
+            (unsigned)(a.nphase == 4 ? ((2 * oy + ppy) * OW + (2 * ox + ppx)) * a.ostride
                        : a.s2d       ? ((oy >> 1) * (a.W >> 1) + (ox >> 1)) * (4 * a.Cout) + ((oy & 1) * 2 + (ox & 1)) * a.Cout
-                                     : (oy * a.W + ox) * a.Cout) * 4u + 16u * oq;
+                                     : (oy * a.W + ox) * a.ostride) * 4u + 16u * oq;
         o.po[ij] = oy < a.H && ox < a.W ? po : 0x80000000u;
       }
     };
@@ -697,8 +698,13 @@ static int wb_launch(wb::Args& a, hipStream_t st) {
   a.tiles_y = ceil_div(H, 8);
   const int64_t nt = (int64_t)a.tiles_x * a.tiles_y * B * a.nphase;
   DSIC_REQUIRE(nt < ((int64_t)1 << 31), "conv_wino_bf16: too many tiles");
+  if (a.ostride <= 0) a.ostride = a.Cout;
+  DSIC_REQUIRE(a.ooff >= 0 && a.ooff % 4 == 0 && a.ostride % 4 == 0 && a.ooff + a.Cout <= a.ostride,
+               "conv_wino_bf16: output slice [%d, %d) does not fit a pixel stride of %d channels", a.ooff,
+               a.ooff + a.Cout, a.ostride);
+  DSIC_REQUIRE(a.ostride == a.Cout || !a.s2d, "conv_wino_bf16: a Cout slice cannot be stored space-to-depth");
   DSIC_REQUIRE((int64_t)H * W * a.Cin * 4 < ((int64_t)1 << 31) &&
-                   (int64_t)H * W * a.Cout * 4 * (a.nphase == 4 ? 4 : 1) < ((int64_t)1 << 31),
+                   (int64_t)H * W * a.ostride * 4 * (a.nphase == 4 ? 4 : 1) < ((int64_t)1 << 31),
                "conv_wino_bf16: one image must stay below 2 GiB (32-bit offsets inside an image)");
   DSIC_REQUIRE(a.u_phase_bytes * a.nphase < ((int64_t)1 << 31), "conv_wino_bf16: transformed weights must stay below 2 GiB");
   a.ntiles = (int)nt;
@@ -741,7 +747,7 @@ static int wb_launch(wb::Args& a, hipStream_t st) {
 extern "C" int dsic_conv3x3_wino_bf16_nhwc(const float* in, const void* u_planes, const float* bias,
                                            const float* beta, const float* gamma, float* out, int B, int H,
                                            int W, int Cin, int Cout, int act, int s2d_out, int s2d_in,
-                                           void* ticket, void* stream) {
+                                           int out_cstride, int out_coff, void* ticket, void* stream) {
   DSIC_REQUIRE(in && u_planes && bias && out && ticket, "conv3x3_wino_bf16: null pointer");
   DSIC_REQUIRE(B > 0 && H > 0 && W > 0, "conv3x3_wino_bf16: empty tensor");
   DSIC_REQUIRE(Cin >= 64 && Cin % 32 == 0, "conv3x3_wino_bf16: Cin=%d must be a multiple of 32, >= 64", Cin);
@@ -754,6 +760,7 @@ extern "C" int dsic_conv3x3_wino_bf16_nhwc(const float* in, const void* u_planes
   a.in = in; a.u = u_planes; a.bias = bias; a.beta = beta; a.gamma = gamma; a.out = out;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.CoutP = round_up(Cout, 32); a.act = act;
   a.s2d = s2d_out; a.s2d_in = s2d_in ? 1 : 0;
+  a.ostride = out_cstride; a.ooff = out_coff;
   a.ticket = (unsigned long long*)ticket;
   a.nphase = 1; a.u_phase_bytes = dsic_wino_bf16_weight_bytes(Cout, Cin);
   return wb_launch(a, (hipStream_t)stream);

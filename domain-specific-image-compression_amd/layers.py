@@ -115,8 +115,29 @@ class Conv2d(_ConvBase):
     def use_winograd_s2(self):
         """5x5 stride-2 layers run as a 3x3 Winograd conv over the space-to-depth input (4*Cin
         channels) when the producing layer can write that layout."""
-        return (USE_WINOGRAD and self.kernel_size == 5 and self.stride == 2 and self.in_channels % 8 == 0
-                and self.out_channels % 4 == 0 and 64 <= self.out_channels <= 128)
+        if not (USE_WINOGRAD and self.kernel_size == 5 and self.stride == 2 and self.in_channels % 8 == 0
+                and self.out_channels % 4 == 0 and self.out_channels >= 64):
+            return False
+        # wider outputs (g_a.14: 128 -> 192, layers.py:72) run as channel slices of <= 128 into one tensor;
+        # only the split-bf16 kernel can store a slice
+        return self.out_channels <= 128 or (WINO_BF16 and self.out_channels <= 256 and 4 * self.in_channels >= 64)
+
+    def _cout_slices(self):
+        """(lo, hi) output-channel slices of at most 128 (multiples of 32 except the last)."""
+        n = self.out_channels
+        return [(lo, min(lo + 128, n)) for lo in range(0, n, 128)]
+
+    def packed_wino_slices(self):
+        """per Cout slice: (lo, hi, bf16 planes, bias, ...) for out_channels > 128 (space-to-depth 5x5/s2 only)"""
+        key = self._key()
+        if getattr(self, "_wino_sl", None) is None or self._wino_sl_key != key:
+            sl = []
+            for lo, hi in self._cout_slices():
+                u = ops.pack_wino_s2_weight(self.weight[lo:hi].contiguous())
+                u = ops.split_wino_weight_bf16(u, hi - lo, 4 * self.in_channels, 1)
+                sl.append((lo, hi, u, self.bias[lo:hi].contiguous()))
+            self._wino_sl, self._wino_sl_key = sl, key
+        return self._wino_sl
 
     def packed_wino(self):
         key = self._key()
@@ -135,6 +156,16 @@ class Conv2d(_ConvBase):
         beta = gamma = None
         if gdn is not None:
             beta, gamma = gdn.effective()
+        if x_is_s2d and self.out_channels > 128:
+            B, H2, W2, _ = x.shape
+            assert not s2d_out
+            out = torch.empty((B, H2, W2, self.out_channels), dtype=torch.float32, device=x.device)
+            for lo, hi, u, bias in self.packed_wino_slices():
+                ops.conv3x3_wino_nhwc(x, u, bias, hi - lo, act, None if beta is None else beta[lo:hi].contiguous(),
+                                      None if gamma is None else gamma[lo:hi].contiguous(), out=out, s2d_in=True,
+                                      out_coff=lo,
+                                      algo_flops=2.0 * B * H2 * W2 * (hi - lo) * self.in_channels * 25)
+            return out
         if x_is_s2d:
             B, H2, W2, _ = x.shape
             return ops.conv3x3_wino_nhwc(x, self.packed_wino(), self.bias, self.out_channels, act, beta, gamma,

@@ -249,7 +249,7 @@ def depth_to_space(x_s2d):
 
 
 def conv3x3_wino_nhwc(x, u_packed, bias, Cout, act=ACT_NONE, beta=None, gamma=None, out=None, s2d_out=False,
-                      algo_flops=None, s2d_in=False):
+                      algo_flops=None, s2d_in=False, out_coff=0):
     """conv(Cin,Cout,3,1) + fused activation by Winograd F(2x2,3x3) on NHWC activations.
 
     s2d_out: write [B,H/2,W/2,4*Cout] (space-to-depth) for a following 5x5/s2 layer."""
@@ -266,7 +266,9 @@ def conv3x3_wino_nhwc(x, u_packed, bias, Cout, act=ACT_NONE, beta=None, gamma=No
                algo_flops if algo_flops is not None else 2.0 * B * H * W * Cout * Cin * 9,
                lambda: _lib.check(L.dsic_conv3x3_wino_bf16_nhwc(_p(x), _p(u_packed), _p(bias), _p(beta), _p(gamma),
                                                                 _p(out), B, H, W, Cin, Cout, act, int(bool(s2d_out)),
-                                                                int(bool(s2d_in)), _p(_ticket(x.device)), _stream()),
+                                                                int(bool(s2d_in)),
+                                                                0 if s2d_out else int(out.shape[-1]), int(out_coff),
+                                                                _p(_ticket(x.device)), _stream()),
                                   "conv3x3_wino_bf16_nhwc"),
                exec_flops=2.0 * nprod * wino_tiles * (12.25 if s2d_in else 16) * Cin * round_up(Cout, 32))
         return out

@@ -143,7 +143,10 @@ int dsic_conv_transpose2d_wino_nhwc(const float* in, const float* u_packed4,
  * dsic_pack_wino_s2_weight (nphase 1) or dsic_pack_wino_convT_weight (nphase 4); dst:
  * nphase * dsic_wino_bf16_weight_bytes(Cout, Cin) bytes, [phase][16][Cin/16][planes][CoutP][16] bf16.
  * The two conv entry points mirror dsic_conv3x3_wino_nhwc / dsic_conv_transpose2d_wino_nhwc
- * (same layers of code/modelv2/layers.py:54-72, 83-97, 108-124; Cin a multiple of 32, >= 64). */
+ * (same layers of code/modelv2/layers.py:54-72, 83-97, 108-124; Cin a multiple of 32, >= 64).
+ * out_cstride / out_coff (floats; 0 / 0 = a dense [B,H,W,Cout] output): the Cout <= 128 channels of this
+ * call are a slice of a wider NHWC tensor - conv(128,192,5,2) (layers.py:72) runs as a 128- and a
+ * 64-channel call into one [B,H,W,192] tensor. */
 int dsic_wino_bf16_planes(void);
 int64_t dsic_wino_bf16_weight_bytes(int Cout, int Cin);
 int dsic_split_wino_weight_bf16(const float* u_f32, void* dst, int Cout, int Cin,
@@ -152,7 +155,7 @@ int dsic_conv3x3_wino_bf16_nhwc(const float* in, const void* u_planes,
                                 const float* bias, const float* beta,
                                 const float* gamma, float* out, int B, int H, int W,
                                 int Cin, int Cout, int act, int s2d_out, int s2d_in,
-                                void* ticket, void* stream);
+                                int out_cstride, int out_coff, void* ticket, void* stream);
 int dsic_conv_transpose2d_wino_bf16_nhwc(const float* in, const void* u_planes4,
                                          const float* bias, const float* beta,
                                          const float* gamma, float* out, int B,

@@ -320,3 +320,28 @@ def test_conv_transpose_winograd_vs_oracle(ops, B, Cin, Cout, H, W, act, variant
     err = float((got - ref).abs().max())
     print(f"[{variant}] err/|ref|max = {err / float(ref.abs().max()):.2e}")
     assert err <= _tol(ref, Cin * 9) * 6 * _BF16_TOL[variant], (err, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 32, 32), (1, 20, 36)])
+def test_conv5x5_stride2_192_channels_as_two_winograd_slices(ops, B, H, W):
+    """g_a.14, conv(128, 192, 5, 2) (layers.py:72): 192 output channels run as a 128- and a 64-channel
+    call of the split-bf16 Winograd kernel into one [B,H/2,W/2,192] tensor (out_cstride / out_coff)."""
+    from dsic_amd import layers as Lm
+    if not Lm.WINO_BF16:
+        pytest.skip("channel slices exist in the split-bf16 kernel only")
+    x = _rand((B, 128, H, W), 81, 2.0)
+    m = Lm.Conv2d(128, 192, 5, 2)
+    w = _rand((192, 128, 5, 5), 82, (128 * 25) ** -0.5 * 2)
+    b = _rand((192,), 83, 0.5)
+    with torch.no_grad():
+        m.weight.copy_(w)
+        m.bias.copy_(b)
+    m = m.cuda()
+    assert m.use_winograd_s2
+    ref = O._conv({"p.weight": w, "p.bias": b}, "p", x, 2)
+    xs = ops.space_to_depth(_nhwc(x).cuda())
+    y = m.run_nhwc(xs, x_is_s2d=True)
+    got = ops.nhwc_to_nchw(y).cpu()
+    assert got.shape == ref.shape
+    err = float((got - ref).abs().max())
+    assert err <= _tol(ref, 128 * 25) * 6 * _BF16_TOL["bf16"], (err, float(ref.abs().max()))
