@@ -19,6 +19,9 @@ echo "p5"; timeout -k 10 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_A
 echo "plain runs"
 python3 bench.py > $G/bench_config3.json 2> $G/bench_config3.err
 python3 bench.py --no-entropy > $G/bench_config2.json 2> $G/bench_config2.err
-python3 bench.py --size 512 --channels 4 --batch 32 --steps 5 --warmup 2 > $G/bench_config5.json 2> $G/bench_config5.err
+python3 bench.py --size 512 --channels 4 --batch 32 --steps 12 --warmup 3 > $G/bench_config5.json 2> $G/bench_config5.err
 ls $G/p1 $G/p2 $G/p3 $G/p5
 tail -c 600 $G/bench_config5.json
+python3 tools/fixture_parity.py > $G/parity_bf16.txt 2>/dev/null
+DSIC_WINO_BF16=0 python3 tools/fixture_parity.py > $G/parity_fp32.txt 2>/dev/null
+DSIC_WINO_BF16=0 python3 bench.py --no-cpu-baseline > $G/bench_config3_fp32kernels.json 2> /dev/null
