@@ -145,7 +145,7 @@ struct Tile {
   int item, tx, ty, n;
 };
 
-template <int MODE>
+template <int MODE, bool NT_OUT>
 __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   float* const yreg = (float*)(lds_raw + YOFF);
@@ -224,6 +224,10 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
         const bool ok = i < WINW * WINH * 4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         m.off[j] = ok ? (unsigned)(((gy * a.W + gx) * Cin + 4 * q) * 4) : 0x80000000u;
       }
+    };
+    auto aim_nowhere = [&](WinAim& m) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) m.off[j] = 0x80000000u;
     };
     auto issue = [&](floatx4 (&r)[3], int chunk) {
       if (WB_ABL & 2) return;
@@ -327,18 +331,21 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
     // groups of a tile are copied out one per chunk pair of the NEXT tile: the vector-memory path
     // issues a 1 KB store instruction in >= 16 cycles, and all 64 KB behind one barrier would hold
     // the MFMA waves for thousands of cycles.
+    // No branch inside: a store whose group or channel quad lies beyond Cout gets the out-of-range
+    // offset the hardware drops.  (The compiler's s_waitcnt placement is exact only when every path
+    // through a phase issues the same memory operations: with a conditional copy-out the wait for
+    // the window loads turned into a wait for the stores issued just before - 700 cycles per phase.)
     auto store_group = [&](const OutAim& o, int g) {
       const float* src = yreg + yread;
-      const int ngroups = (a.Cout + 31) >> 5;
-      if (g >= ngroups) return;
-      if (g == ngroups - 1 && g * 32 + 4 * oq >= a.Cout) return;  // partial last group (Cout % 32 != 0)
+      const bool chan_ok = g * 32 + 4 * oq < a.Cout;
 #pragma unroll
       for (int ij = 0; ij < 4; ++ij) {
-        const floatx4 v = *(const floatx4*)(src + (ij * 4 + g) * 32 * WP);
-        if (a.nt_out)
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), o.rs, o.po[ij], g * 128, 2);
+        const floatx4 v = *(const floatx4*)(src + (ij * 4 + (g & 3)) * 32 * WP);
+        const unsigned off = chan_ok ? o.po[ij] : 0x80000000u;
+        if (NT_OUT)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), o.rs, off, g * 128, 2);
         else
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), o.rs, o.po[ij], g * 128, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), o.rs, off, g * 128, 0);
       }
     };
 
@@ -370,20 +377,21 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
     oa.rs = am.rsrc;
 #pragma unroll
     for (int ij = 0; ij < 4; ++ij) oa.po[ij] = 0x80000000u;
-    bool have_y = false;
     int tile_count = 0;
     (void)tile_count;
     while (cur.item < a.ntiles) {
       const Tile nxt = read_slot(s_nxt);
       const bool more = nxt.item < a.ntiles;
       tile_count++;
-      // one phase (tile-local chunk c; targets past the last chunk belong to the next tile)
+      // One phase (tile-local chunk c; targets past the last chunk belong to the next tile).  Every
+      // phase issues the same memory operations whatever the tile: with no next tile the aim points
+      // nowhere (loads return 0 without traffic) and the staged / committed chunks are never read.
       auto phase = [&](floatx4 (&R)[3], int c) {
         WSTAMP(8, 4 * c);
-        if (c + 2 < nchunks || more) stage(R, c & 1);              // window of chunk c+2
+        stage(R, c & 1);                                                 // window of chunk c+2
         WSTAMP(8, 4 * c + 1);
-        if (c + 1 < nchunks || more) {                                   // target c+1
-          unsigned zxi, znu;
+        {
+          unsigned zxi, znu;                                             // target c+1
           if (c + 1 < nchunks) zero_of(cur.item, c + 1, zxi, znu); else zero_of(nxt.item, 0, zxi, znu);
           commit((c + 1) & 1, (c + 1) & 1, zxi, znu);
         }
@@ -391,19 +399,22 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
         __syncthreads();  // B_c
         WSTAMP(8, 4 * c + 3);
         const int k4 = c + 4;
-        if (k4 < nchunks) {
-          issue(R, k4);
-        } else if (more) {
-          if (k4 == nchunks) aim(am, nxt);      // phase n-4: from here on every load is for the next tile
-          issue(R, k4 - nchunks);
+        if (k4 == nchunks) {   // phase n-4: from here on every load is for the next tile
+          if (more) aim(am, nxt); else aim_nowhere(am);
         }
+        issue(R, k4 < nchunks ? k4 : k4 - nchunks);
       };
-      const int gper = nchunks >= 8 ? 1 : 2;   // output groups copied per chunk pair
-      for (int c = 0; c < nchunks; c += 2) {
-        if (c == 0 && ht == 0 && more) post(s_wr, ticket_pre);
-        if (have_y) {   // outputs of the previous tile (Y is rewritten at this tile's fold)
-          for (int g = (c >> 1) * gper; g < ((c >> 1) + 1) * gper && g < 4; ++g) store_group(oa, g);
-        }
+      if (ht == 0 && more) post(s_wr, ticket_pre);
+      // outputs of the previous tile (Y is rewritten at this tile's fold): one 32-channel group per chunk
+      // pair in the first eight phases (both groups of a pair at once when there are only four phases)
+      const int npair_out = nchunks >= 8 ? 4 : 2;
+      for (int c = 0; c < 2 * npair_out; c += 2) {
+        store_group(oa, nchunks >= 8 ? (c >> 1) : c);
+        if (nchunks < 8) store_group(oa, c + 1);
+        phase(R0, c);
+        phase(R1, c + 1);
+      }
+      for (int c = 2 * npair_out; c < nchunks; c += 2) {
         phase(R0, c);
         phase(R1, c + 1);
       }
@@ -411,15 +422,12 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
       aim_out(oa, cur);
       __syncthreads();  // E1
       __syncthreads();  // E2
-      have_y = true;
       cur = nxt;
       const int s_old = s_nxt;
       s_nxt = s_wr;
       s_wr = s_old == 0 ? 2 : s_old - 1;
     }
-    if (have_y) {
-      for (int g = 0; g < 4; ++g) store_group(oa, g);
-    }
+    for (int g = 0; g < 4; ++g) store_group(oa, g);   // outputs of the last tile (dropped offsets if there was none)
 #if WB_STAMP
     if (wave == 8) {
       wb_stamps[blockIdx.x * 128 + lane] = ((long long*)(lds_raw + STAMPOFF))[lane];
@@ -714,17 +722,15 @@ static int wb_launch(wb::Args& a, hipStream_t st) {
   static bool attr_set[64] = {};
   if (dev < 0 || dev >= 64) dev = 0;
   if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute((const void*)wb::conv_wino_bf16_kernel<0>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, wb::LDS_TOTAL);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)wb::conv_wino_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              wb::LDS_TOTAL);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)wb::conv_wino_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              wb::LDS_TOTAL);
-    if (e != hipSuccess) {
-      set_error("conv_wino_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return DSIC_EHIP;
+    const void* fns[6] = {(const void*)wb::conv_wino_bf16_kernel<0, false>, (const void*)wb::conv_wino_bf16_kernel<1, false>,
+                          (const void*)wb::conv_wino_bf16_kernel<2, false>, (const void*)wb::conv_wino_bf16_kernel<0, true>,
+                          (const void*)wb::conv_wino_bf16_kernel<1, true>,  (const void*)wb::conv_wino_bf16_kernel<2, true>};
+    for (int i = 0; i < 6; ++i) {
+      const hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, wb::LDS_TOTAL);
+      if (e != hipSuccess) {
+        set_error("conv_wino_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return DSIC_EHIP;
+      }
     }
     attr_set[dev] = true;
   }
@@ -735,12 +741,20 @@ static int wb_launch(wb::Args& a, hipStream_t st) {
     if (max_grid < 1 || max_grid > 1024) max_grid = 256;
   }
   const int grid = a.ntiles < max_grid ? a.ntiles : max_grid;
+#define WB_LAUNCH(M)                                                                                          \
+  do {                                                                                                        \
+    if (a.nt_out)                                                                                             \
+      hipLaunchKernelGGL((wb::conv_wino_bf16_kernel<M, true>), dim3(grid), dim3(wb::THREADS), wb::LDS_TOTAL, st, a);  \
+    else                                                                                                      \
+      hipLaunchKernelGGL((wb::conv_wino_bf16_kernel<M, false>), dim3(grid), dim3(wb::THREADS), wb::LDS_TOTAL, st, a); \
+  } while (0)
   if (a.s2d_in)
-    hipLaunchKernelGGL(wb::conv_wino_bf16_kernel<1>, dim3(grid), dim3(wb::THREADS), wb::LDS_TOTAL, st, a);
+    WB_LAUNCH(1);
   else if (a.nphase == 4)
-    hipLaunchKernelGGL(wb::conv_wino_bf16_kernel<2>, dim3(grid), dim3(wb::THREADS), wb::LDS_TOTAL, st, a);
+    WB_LAUNCH(2);
   else
-    hipLaunchKernelGGL(wb::conv_wino_bf16_kernel<0>, dim3(grid), dim3(wb::THREADS), wb::LDS_TOTAL, st, a);
+    WB_LAUNCH(0);
+#undef WB_LAUNCH
   return check_launch("conv_wino_bf16");
 }
 
