@@ -293,6 +293,35 @@ def to_tensor_u8(x_u8_nhwc: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def pack_conv5s2_bf16_weight(w: torch.Tensor) -> torch.Tensor:
+    """nn.Conv2d(Cs, Cout, 5, stride 2) weight [Cout,Cs,5,5] -> bf16 planes of the direct split-bf16 kernel."""
+    w = _f32c(w, "pack_conv5s2_bf16_weight")
+    Cout, Cs, k, k2 = w.shape
+    if k != 5 or k2 != 5:
+        raise ValueError("pack_conv5s2_bf16_weight: kernel must be 5x5")
+    L = _lib.load()
+    dst = torch.empty(L.dsic_conv5s2_bf16_weight_bytes(Cout, Cs), dtype=torch.uint8, device=w.device)
+    _lib.check(L.dsic_pack_conv5s2_bf16_weight(_p(w), _p(dst), Cout, Cs, _stream()), "pack_conv5s2_bf16_weight")
+    return dst
+
+
+def conv5s2_bf16_nhwc(x_s2d, w_planes, bias, Cout, act=ACT_NONE, beta=None, gamma=None):
+    """conv(Cs,Cout,5,2) + fused activation, direct split-bf16 implicit GEMM over the space-to-depth image
+    x_s2d [B,H,W,4*Cs] -> [B,H,W,Cout]."""
+    x = _f32c(x_s2d, "conv5s2_bf16_nhwc")
+    B, H, W, C4 = x.shape
+    Cs = C4 // 4
+    out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+    L = _lib.load()
+    tiles = B * (-(-H // 8)) * (-(-W // 16))
+    _timed("conv5s2_bf16_kernel", 2.0 * B * H * W * Cout * Cs * 25,
+           lambda: _lib.check(L.dsic_conv5s2_bf16_nhwc(_p(x), _p(w_planes), _p(bias), _p(beta), _p(gamma), _p(out), B, H, W,
+                                                       Cs, Cout, act, _p(_ticket(x.device)), _stream()),
+                              "conv5s2_bf16_nhwc"),
+           exec_flops=2.0 * 3 * tiles * 128 * 25 * Cs * round_up(Cout, 32))
+    return out
+
+
 def conv_first_nchw(x, w, bias, act=ACT_NONE, beta=None, gamma=None, s2d_out=False):
     """conv(Cimg,Cout,3,1) + fused activation from the image to NHWC (layers.py:51).
     x: float32 NCHW in [0,1] (the reference's tensor contract), or uint8 NHWC image bytes

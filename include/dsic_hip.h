@@ -162,6 +162,19 @@ int dsic_conv_transpose2d_wino_bf16_nhwc(const float* in, const void* u_planes4,
                                          int H, int W, int Cin, int Cout, int act,
                                          void* ticket, void* stream);
 
+/* conv(Cs, Cout, 5, stride 2) + bias + GDN/ReLU (code/modelv2/layers.py:54,60,65) as a direct implicit
+ * GEMM on split-bf16 MFMAs over the space-to-depth image [B][H][W][4*Cs] (H, W = output size) that the
+ * producing layer writes (csrc/conv5s2_bf16.hip): 25 live (tap, channel block) pairs, half the weight
+ * bytes of the Winograd form.  Cs a multiple of 16, >= 64; Cout <= 128.  Weights from the reference's
+ * [Cout][Cs][5][5] tensor by dsic_pack_conv5s2_bf16_weight (dsic_conv5s2_bf16_weight_bytes bytes). */
+int64_t dsic_conv5s2_bf16_weight_bytes(int Cout, int Cs);
+int dsic_pack_conv5s2_bf16_weight(const float* w_oihw5, void* dst, int Cout, int Cs,
+                                  void* stream);
+int dsic_conv5s2_bf16_nhwc(const float* in_s2d, const void* w_planes, const float* bias,
+                           const float* beta, const float* gamma, float* out, int B,
+                           int H, int W, int Cs, int Cout, int act, void* ticket,
+                           void* stream);
+
 /* First analysis layer conv(Cimg,Cout,3,1) + optional GDN/ReLU (layers.py:51)
  * read straight from the NCHW image [B,Cimg,H,W] (Cimg 3 or 4) with K = 9*Cimg;
  * w_oihw is the reference weight [Cout,Cimg,3,3] unpacked; out NHWC [B,H,W,Cout],
