@@ -6,6 +6,8 @@ reference's nine keys with the reference's NCHW shapes (model.py:65-72).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -24,6 +26,13 @@ class ForwardOutput(dict):
     layer_taps = None
 
 
+# The hyperprior branch (h_a, round z, h_s, the rate terms and the `after_rate` hook: 9 launches on 4x4..16x16
+# latents, a few dozen workgroups each, ~0.5 ms of dependent launches at 256x256) needs only y; synthesis needs only
+# round(y).  forward() therefore forks: the branch runs on a second, high-priority HIP stream beside g_s and is
+# joined before forward() returns.  DSIC_HYPER_STREAM=0 keeps everything on the caller's stream.
+HYPER_STREAM = os.environ.get("DSIC_HYPER_STREAM", "1") != "0"
+
+
 class CompressionModel(nn.Module):
     def __init__(self, N=128, M=192, spatial_params=False, min_nu=1.1, max_nu=100.0, in_ch=3):
         super().__init__()
@@ -37,6 +46,15 @@ class CompressionModel(nn.Module):
         self.max_nu = max_nu
         self.spatial_params = spatial_params
         self.N, self.M = N, M
+        self._fork = {}              # device index -> (side stream, fork event, join event)
+
+    def _hyper_fork(self, device):
+        f = self._fork.get(device.index)
+        if f is None:
+            with torch.cuda.device(device):
+                f = (torch.cuda.Stream(priority=-1), torch.cuda.Event(), torch.cuda.Event())
+            self._fork[device.index] = f
+        return f
 
     @staticmethod
     def quantize(x, mode):
@@ -67,22 +85,36 @@ class CompressionModel(nn.Module):
             B, _, H, W = x.shape
         taps = [] if collect_taps else None
         y = self.g_a.forward_from_image(x, taps)           # [B,H/16,W/16,M]
-        z = self.h_a.forward_nhwc(y, taps)                 # [B,.,.,N]
-        y_noisy = z_noisy = None
-        if quant_mode == "noise":
-            y_noisy = self.quantize(y, "noise")
-            z_noisy = self.quantize(z, "noise")
-            z_in = z_noisy
-        else:
-            z_in = ops.round_half_even(z)
-        (log_sigma, log_nu, sigma, nu), _ = self.h_s.params_nhwc(z_in, self.min_nu, self.max_nu, taps)
-        r = ops.rate(y, z, sigma, nu, self.z_prior.log_sigma, y_noisy, z_noisy)
-        if after_rate is not None:
-            after_rate({"y_tilde": r["y_tilde"], "z_tilde": r["z_tilde"], "sigma": sigma, "nu": nu,
-                        "sums": r["sums"]})
+        y_noisy = self.quantize(y, "noise") if quant_mode == "noise" else None
         # model.py:62: eval mode synthesises from round(y), training from y_tilde
-        y_hat = r["y_hat_nhwc"] if not self.training else (y_noisy if y_noisy is not None else r["y_hat_nhwc"])
-        x_hat = self.g_s.forward_nhwc(y_hat, taps)
+        y_hat = y_noisy if (self.training and y_noisy is not None) else ops.round_half_even(y)
+
+        def hyper_branch():
+            z = self.h_a.forward_nhwc(y, taps)             # [B,.,.,N]
+            z_noisy = self.quantize(z, "noise") if quant_mode == "noise" else None
+            z_in = z_noisy if z_noisy is not None else ops.round_half_even(z)
+            (log_sigma, log_nu, sigma, nu), _ = self.h_s.params_nhwc(z_in, self.min_nu, self.max_nu, taps)
+            r = ops.rate(y, z, sigma, nu, self.z_prior.log_sigma, y_noisy, z_noisy)
+            if after_rate is not None:
+                after_rate({"y_tilde": r["y_tilde"], "z_tilde": r["z_tilde"], "sigma": sigma, "nu": nu,
+                            "sums": r["sums"]})
+            return z, sigma, nu, r
+
+        if HYPER_STREAM:
+            main = torch.cuda.current_stream(y.device)
+            side, forked, joined = self._hyper_fork(y.device)
+            forked.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(forked)
+                z, sigma, nu, r = hyper_branch()
+                joined.record(side)
+            x_hat = self.g_s.forward_nhwc(y_hat, taps)
+            # the branch's tensors live in the side stream's pool; every later use on `main` is ordered after
+            # this join, and the next fork waits for `main`, so the pool never recycles them under a reader
+            main.wait_event(joined)
+        else:
+            z, sigma, nu, r = hyper_branch()
+            x_hat = self.g_s.forward_nhwc(y_hat, taps)
         Hy, Wy = y.shape[1], y.shape[2]
         out = ForwardOutput({
             "x_hat": x_hat,

@@ -163,3 +163,34 @@ def test_uint8_image_ingest_equals_to_tensor_path():
         odd = u8[:, : H - 5, : W - 3].contiguous().cuda()
         rows_o = evaluate.evaluate_batch(m, odd)
         assert rows_o == evaluate.evaluate_batch(m, ops.to_tensor_u8(odd))
+
+
+def test_hyper_branch_on_second_stream_gives_the_same_bits():
+    """forward() runs h_a / h_s / the rate terms on a second HIP stream beside g_s (model.HYPER_STREAM);
+    the result is bit-identical to the single-stream order, also when forward() is called back to back
+    (the branch's tensors come from the side stream's allocator pool) and with an after_rate hook."""
+    from dsic_amd import entropy, model as M
+    m, _ = build_model(1, 3)
+    xs = [torch.from_numpy(S.make_patches(40 + 8 * i, 8, 128, 128)).cuda() for i in range(3)]
+    keys = ("x_hat", "nll_y", "nll_z", "y", "y_tilde", "z", "z_tilde", "sigma", "nu")
+    saved = M.HYPER_STREAM
+    try:
+        M.HYPER_STREAM = False
+        ref = [m(x, quant_mode="round") for x in xs]
+        ref_strings = entropy.custom_compress(m, xs[0])["strings"]
+        M.HYPER_STREAM = True
+        for _ in range(3):                       # back to back, outputs dropped in between
+            outs = [m(x, quant_mode="round") for x in xs]
+        coder = entropy.AsyncCompressor(m)
+        hooked = m(xs[0], quant_mode="round", after_rate=coder)
+        coder.wait()
+        strings = entropy.custom_compress(m, xs[0])["strings"]
+    finally:
+        M.HYPER_STREAM = saved
+    torch.cuda.synchronize()
+    for a, b in zip(ref, outs):
+        for k in keys:
+            assert torch.equal(a[k], b[k]), k
+        assert torch.equal(a.sums, b.sums)
+    assert torch.equal(hooked["x_hat"], ref[0]["x_hat"]) and torch.equal(hooked.sums, ref[0].sums)
+    assert strings == ref_strings
