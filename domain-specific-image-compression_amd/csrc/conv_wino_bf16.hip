@@ -79,6 +79,10 @@ struct Args {
   int tiles_x, tiles_y, ntiles;
   int nt_out;
   int ostride, ooff;  // output pixel stride and channel offset in floats (a Cout slice of a wider tensor)
+  // split-K: a work item is (tile, ks); it walks kchunks = Cin/16/ksplit chunks from ks*kchunks and writes its
+  // un-biased, un-activated sums into out + ks*part_stride (same addressing); splitk_reduce_kernel finishes
+  int ksplit, kchunks;
+  int64_t part_stride;
 };
 
 constexpr int P = WB_PLANES;
@@ -142,10 +146,12 @@ __device__ __forceinline__ float bf16_lo(unsigned pk) { return __builtin_bit_cas
 __device__ __forceinline__ float bf16_hi(unsigned pk) { return __builtin_bit_cast(float, pk & 0xFFFF0000u); }
 
 struct Tile {
-  int item, tx, ty, n;
+  int item, tx, ty, n, ks;
 };
 
-template <int MODE, bool NT_OUT>
+// SPLITK is a template parameter: the unsplit kernels keep their register allocation (with the work item's chunk
+// offset as run-time state the 3x3 kernel spilled 20 more SGPRs into its loops and ran 20 % slower).
+template <int MODE, bool NT_OUT, bool SPLITK>
 __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   float* const yreg = (float*)(lds_raw + YOFF);
@@ -157,12 +163,15 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
     Tile t;
     t.item = __builtin_amdgcn_readfirstlane(v[0]);
     t.tx = __builtin_amdgcn_readfirstlane(v[1]);
-    t.ty = __builtin_amdgcn_readfirstlane(v[2]);
+    t.ty = SPLITK ? __builtin_amdgcn_readfirstlane(v[2]) & 0xFFFF : __builtin_amdgcn_readfirstlane(v[2]);
+    t.ks = SPLITK ? __builtin_amdgcn_readfirstlane(v[2]) >> 16 : 0;
     t.n = __builtin_amdgcn_readfirstlane(v[3]);
     return t;
   };
   const int pshift = a.nphase == 4 ? 2 : 0;
-  const int nchunks = a.Cin / CK;  // even, >= 4 (host)
+  const int tchunks = a.Cin / CK;                    // = nchunks * ksplit
+  const int nchunks = SPLITK ? a.kchunks : tchunks;  // chunks of one work item: even, >= 4 (host)
+  const int ksplit = SPLITK ? a.ksplit : 1;
 
   if (wave >= 8) {
     // =================================== helper waves ===========================================
@@ -186,10 +195,11 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
     const int ot = ht >> 3, oq = ht & 7;
     const int otx = ot & 7, oty = ot >> 3;
     const int yread = ot * WP + 4 * oq;
-    auto post = [&](int s, int item) {  // helper thread 0 only
+    auto post = [&](int s, int t) {  // helper thread 0 only; ticket t = item * ksplit + ks
+      const int item = SPLITK ? t / ksplit : t, ks = SPLITK ? t - item * ksplit : 0;
       const int tile = item >> pshift;
       const int row = tile / a.tiles_x;
-      const intx4 v = {item, tile - row * a.tiles_x, row % a.tiles_y, row / a.tiles_y};
+      const intx4 v = {item, tile - row * a.tiles_x, (row % a.tiles_y) | (ks << 16), row / a.tiles_y};
       *(intx4*)(slots + 4 * s) = v;
     };
     // Input side.  The 18x10-pixel window of the tile (halo 1; 16 channels of the chunk, fp32) is
@@ -203,6 +213,7 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
     // so a global load has two phases to arrive, a staged window one barrier to become visible.
     struct WinAim {
       unsigned off[3];   // byte offsets of this thread's (pixel, quad) items inside the image (out of range = 0)
+      unsigned coff;     // byte offset of the work item's first chunk inside a pixel
       __amdgpu_buffer_rsrc_t rsrc;
     };
     WinAim am;
@@ -215,6 +226,7 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
     auto aim = [&](WinAim& m, const Tile& t) {
       m.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)t.n * a.H * a.W * Cin), 0,
                                                  a.H * a.W * Cin * 4, 0x00020000);
+      m.coff = (unsigned)(t.ks * nchunks * (CK * 4));
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int i = ht + 256 * j;
@@ -226,6 +238,7 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
       }
     };
     auto aim_nowhere = [&](WinAim& m) {
+      m.coff = 0;
 #pragma unroll
       for (int j = 0; j < 3; ++j) m.off[j] = 0x80000000u;
     };
@@ -233,7 +246,7 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
       if (WB_ABL & 2) return;
 #pragma unroll
       for (int j = 0; j < 3; ++j)
-        r[j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(am.rsrc, am.off[j], chunk * (CK * 4), 0));
+        r[j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(am.rsrc, am.off[j], am.coff + chunk * (CK * 4), 0));
     };
     auto stage = [&](const floatx4 (&r)[3], int wbuf) {
       unsigned char* wb = lds_raw + STAGEOFF + wbuf * WINB;
@@ -292,15 +305,15 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
       }
     };
     // zero row / column of tile-local chunk k of work item `item` (MODE 1: by channel block; MODE 2: by phase)
-    auto zero_of = [&](int item, int k, unsigned& zxi, unsigned& znu) {
+    auto zero_of = [&](const Tile& t, int k, unsigned& zxi, unsigned& znu) {
       zxi = 4;
       znu = 4;
       if (MODE == 1) {
-        const int blk = k / (nchunks >> 2);
+        const int blk = (t.ks * nchunks + k) / (tchunks >> 2);
         if (blk >> 1) zxi = 3;
         if (blk & 1) znu = 3;
       } else if (MODE == 2) {
-        const int phase = item & 3;
+        const int phase = t.item & 3;
         if (phase >> 1) zxi = 0;
         if (phase & 1) znu = 0;
       }
@@ -314,7 +327,8 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
       const int phase = t.item & (a.nphase - 1);
       const int ppy = phase >> 1, ppx = phase & 1;
       const int OH = a.nphase == 4 ? 2 * a.H : a.H, OW = a.nphase == 4 ? 2 * a.W : a.W;
-      o.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)t.n * OH * OW * a.ostride + a.ooff), 0,
+      o.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (SPLITK ? (size_t)t.ks * a.part_stride : (size_t)0) +
+                                                       (size_t)t.n * OH * OW * a.ostride + a.ooff), 0,
                                                (OH * OW * a.ostride - a.ooff) * 4, 0x00020000);
 #pragma unroll
       for (int ij = 0; ij < 4; ++ij) {
@@ -356,7 +370,7 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
     __syncthreads();  // P0
     Tile cur = read_slot(0);
     floatx4 R0[3], R1[3];
-    int ticket_pre = a.ntiles;
+    int ticket_pre = a.ntiles * ksplit;
     aim(am, cur);
     issue(R0, 0);
     issue(R1, 1);
@@ -368,7 +382,7 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
     __syncthreads();  // P1: windows of chunks 0 and 1 are staged
     {
       unsigned zxi, znu;
-      zero_of(cur.item, 0, zxi, znu);
+      zero_of(cur, 0, zxi, znu);
       commit(0, 0, zxi, znu);    // V[0] = (cur, 0)
     }
     __syncthreads();  // P
@@ -392,7 +406,7 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
         WSTAMP(8, 4 * c + 1);
         {
           unsigned zxi, znu;                                             // target c+1
-          if (c + 1 < nchunks) zero_of(cur.item, c + 1, zxi, znu); else zero_of(nxt.item, 0, zxi, znu);
+          if (c + 1 < nchunks) zero_of(cur, c + 1, zxi, znu); else zero_of(nxt, 0, zxi, znu);
           commit((c + 1) & 1, (c + 1) & 1, zxi, znu);
         }
         WSTAMP(8, 4 * c + 2);
@@ -453,7 +467,7 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
   // U stream: [pos][chunk][plane][CoutP][16 bf16]; a fragment = 64 lanes x 16 bytes
   const unsigned plane_b = (unsigned)a.CoutP * 32u;
   const unsigned chunk_b = plane_b * (unsigned)P;
-  const unsigned pos_b = chunk_b * (unsigned)nchunks;
+  const unsigned pos_b = chunk_b * (unsigned)tchunks;
   const unsigned ulane = (unsigned)((((nvalid ? nt : 0) * 32 + l31) * 2 + h) * 16);
   auto pos_of = [](int pi) { return PDIR > 0 ? pi : 7 - pi; };
   // V reads: row l31 of position ph*8+p, k-block h (swizzled)
@@ -462,7 +476,7 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
   {
     const int col = nt * 32 + l31;
     if (col < a.Cout) {
-      pbias = a.bias[col];
+      pbias = SPLITK ? 0.f : a.bias[col];
       if (a.act == DSIC_ACT_GDN || a.act == DSIC_ACT_IGDN) {
         pbeta = a.beta[col];
         pgamma = a.gamma[col];
@@ -478,7 +492,11 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
   const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.u, 0, (int)(16u * pos_b * (unsigned)a.nphase), 0x00020000);
   // fetch stream position: (tile's phase, chunk, position index pi) -> scalar byte offset
-  unsigned soff_phase = (unsigned)(cur.item & (a.nphase - 1)) * (unsigned)a.u_phase_bytes;
+  // (+ the work item's first chunk)
+  auto soff_item = [&](const Tile& t) {
+    return (unsigned)(t.item & (a.nphase - 1)) * (unsigned)a.u_phase_bytes + (unsigned)(t.ks * nchunks) * chunk_b;
+  };
+  unsigned soff_phase = soff_item(cur);
   auto soff_of = [&](unsigned phase_off, int chunk, int pi) {
     return phase_off + (unsigned)(ph * 8 + pos_of(pi)) * pos_b + (unsigned)chunk * chunk_b;
   };
@@ -496,15 +514,14 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
   while (cur.item < a.ntiles) {
     tile_count++;
     const Tile nxt = read_slot(s_nxt);
-    const unsigned soff_phase_nxt =
-        (unsigned)((nxt.item < a.ntiles ? nxt.item : cur.item) & (a.nphase - 1)) * (unsigned)a.u_phase_bytes;
+    const unsigned soff_phase_nxt = soff_item(nxt.item < a.ntiles ? nxt : cur);
     auto chunk_body = [&](auto first_tag, int chunk) {
       constexpr bool FIRST = decltype(first_tag)::value;
       const bool last = chunk + 1 == nchunks;
       WSTAMP(0, 3 * chunk);
       unsigned zero_xi = 4, zero_nu = 4;
       if (MODE == 1) {
-        const int blk = chunk / (nchunks >> 2);
+        const int blk = (cur.ks * nchunks + chunk) / (tchunks >> 2);
         if (blk >> 1) zero_xi = 3;
         if (blk & 1) zero_nu = 3;
       } else if (MODE == 2) {
@@ -668,6 +685,35 @@ __global__ void split_u_kernel(const float* __restrict__ u32, unsigned short* __
   }
 }
 
+// split-K epilogue: out = act(sum_ks part[ks] + bias), partial sums added in the fixed order ks = 0..S-1.
+// One thread per (pixel, channel quad); the partial buffers use the output's own addressing.
+template <int ACT>
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, int S, int64_t part_stride, float* __restrict__ out,
+                                     int64_t npix, int C, int cmod, int ostride, int ooff,
+                                     const float* __restrict__ bias, const float* __restrict__ beta,
+                                     const float* __restrict__ gamma) {
+  const int q4 = C >> 2;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * q4) return;
+  const int64_t pix = i / q4;
+  const int c = (int)(i - pix * q4) * 4;
+  const int64_t off = pix * ostride + ooff + c;
+  floatx4 v = *(const floatx4*)(part + off);
+  for (int ks = 1; ks < S; ++ks) v = v + *(const floatx4*)(part + (int64_t)ks * part_stride + off);
+  const int cb = c % cmod;
+  v = v + *(const floatx4*)(bias + cb);
+  if (ACT == DSIC_ACT_GDN || ACT == DSIC_ACT_IGDN) {
+    const floatx4 be = *(const floatx4*)(beta + cb), ga = *(const floatx4*)(gamma + cb);
+    const floatx2 lo = gdn_pair<ACT == DSIC_ACT_IGDN>(floatx2{v[0], v[1]}, floatx2{be[0], be[1]}, floatx2{ga[0], ga[1]});
+    const floatx2 hi = gdn_pair<ACT == DSIC_ACT_IGDN>(floatx2{v[2], v[3]}, floatx2{be[2], be[3]}, floatx2{ga[2], ga[3]});
+    v = floatx4{lo[0], lo[1], hi[0], hi[1]};
+  } else if (ACT == DSIC_ACT_RELU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+  }
+  *(floatx4*)(out + off) = v;
+}
+
 }  // namespace wb
 }  // namespace dsic
 
@@ -705,7 +751,11 @@ static int wb_launch(wb::Args& a, hipStream_t st) {
   a.tiles_x = ceil_div(W, 16);
   a.tiles_y = ceil_div(H, 8);
   const int64_t nt = (int64_t)a.tiles_x * a.tiles_y * B * a.nphase;
-  DSIC_REQUIRE(nt < ((int64_t)1 << 31), "conv_wino_bf16: too many tiles");
+  if (a.ksplit < 1) a.ksplit = 1;
+  a.kchunks = a.Cin / wb::CK / a.ksplit;
+  DSIC_REQUIRE(a.kchunks * a.ksplit * wb::CK == a.Cin && a.kchunks >= 4 && a.kchunks % 2 == 0 && a.ksplit < 256,
+               "conv_wino_bf16: ksplit=%d does not divide Cin=%d into even runs of >= 4 chunks", a.ksplit, a.Cin);
+  DSIC_REQUIRE(nt * a.ksplit < ((int64_t)1 << 31), "conv_wino_bf16: too many tiles");
   if (a.ostride <= 0) a.ostride = a.Cout;
   DSIC_REQUIRE(a.ooff >= 0 && a.ooff % 4 == 0 && a.ostride % 4 == 0 && a.ooff + a.Cout <= a.ostride,
                "conv_wino_bf16: output slice [%d, %d) does not fit a pixel stride of %d channels", a.ooff,
@@ -716,16 +766,17 @@ static int wb_launch(wb::Args& a, hipStream_t st) {
                "conv_wino_bf16: one image must stay below 2 GiB (32-bit offsets inside an image)");
   DSIC_REQUIRE(a.u_phase_bytes * a.nphase < ((int64_t)1 << 31), "conv_wino_bf16: transformed weights must stay below 2 GiB");
   a.ntiles = (int)nt;
-  a.nt_out = (int64_t)B * H * W * a.Cout * 4 * (a.nphase == 4 ? 4 : 1) > (300ll << 20);
+  a.nt_out = a.ksplit == 1 && (int64_t)B * H * W * a.Cout * 4 * (a.nphase == 4 ? 4 : 1) > (300ll << 20);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   static bool attr_set[64] = {};
   if (dev < 0 || dev >= 64) dev = 0;
   if (!attr_set[dev]) {
-    const void* fns[6] = {(const void*)wb::conv_wino_bf16_kernel<0, false>, (const void*)wb::conv_wino_bf16_kernel<1, false>,
-                          (const void*)wb::conv_wino_bf16_kernel<2, false>, (const void*)wb::conv_wino_bf16_kernel<0, true>,
-                          (const void*)wb::conv_wino_bf16_kernel<1, true>,  (const void*)wb::conv_wino_bf16_kernel<2, true>};
-    for (int i = 0; i < 6; ++i) {
+    const void* fns[8] = {(const void*)wb::conv_wino_bf16_kernel<0, false, false>, (const void*)wb::conv_wino_bf16_kernel<1, false, false>,
+                          (const void*)wb::conv_wino_bf16_kernel<2, false, false>, (const void*)wb::conv_wino_bf16_kernel<0, true, false>,
+                          (const void*)wb::conv_wino_bf16_kernel<1, true, false>,  (const void*)wb::conv_wino_bf16_kernel<2, true, false>,
+                          (const void*)wb::conv_wino_bf16_kernel<0, false, true>,  (const void*)wb::conv_wino_bf16_kernel<1, false, true>};
+    for (int i = 0; i < 8; ++i) {
       const hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, wb::LDS_TOTAL);
       if (e != hipSuccess) {
         set_error("conv_wino_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -740,15 +791,22 @@ static int wb_launch(wb::Args& a, hipStream_t st) {
     max_grid = g ? atoi(g) : 256;
     if (max_grid < 1 || max_grid > 1024) max_grid = 256;
   }
-  const int grid = a.ntiles < max_grid ? a.ntiles : max_grid;
+  const int64_t nwork = (int64_t)a.ntiles * a.ksplit;
+  const int grid = nwork < max_grid ? (int)nwork : max_grid;
 #define WB_LAUNCH(M)                                                                                          \
   do {                                                                                                        \
     if (a.nt_out)                                                                                             \
-      hipLaunchKernelGGL((wb::conv_wino_bf16_kernel<M, true>), dim3(grid), dim3(wb::THREADS), wb::LDS_TOTAL, st, a);  \
+      hipLaunchKernelGGL((wb::conv_wino_bf16_kernel<M, true, false>), dim3(grid), dim3(wb::THREADS), wb::LDS_TOTAL, st, a);  \
     else                                                                                                      \
-      hipLaunchKernelGGL((wb::conv_wino_bf16_kernel<M, false>), dim3(grid), dim3(wb::THREADS), wb::LDS_TOTAL, st, a); \
+      hipLaunchKernelGGL((wb::conv_wino_bf16_kernel<M, false, false>), dim3(grid), dim3(wb::THREADS), wb::LDS_TOTAL, st, a); \
   } while (0)
-  if (a.s2d_in)
+  if (a.ksplit > 1) {
+    DSIC_REQUIRE(a.nphase == 1, "conv_wino_bf16: split-K exists for the 3x3 layers only");
+    if (a.s2d_in)
+      hipLaunchKernelGGL((wb::conv_wino_bf16_kernel<1, false, true>), dim3(grid), dim3(wb::THREADS), wb::LDS_TOTAL, st, a);
+    else
+      hipLaunchKernelGGL((wb::conv_wino_bf16_kernel<0, false, true>), dim3(grid), dim3(wb::THREADS), wb::LDS_TOTAL, st, a);
+  } else if (a.s2d_in)
     WB_LAUNCH(1);
   else if (a.nphase == 4)
     WB_LAUNCH(2);
@@ -778,6 +836,61 @@ extern "C" int dsic_conv3x3_wino_bf16_nhwc(const float* in, const void* u_planes
   a.ticket = (unsigned long long*)ticket;
   a.nphase = 1; a.u_phase_bytes = dsic_wino_bf16_weight_bytes(Cout, Cin);
   return wb_launch(a, (hipStream_t)stream);
+}
+
+// Split-K policy, a function of the layer's geometry only (never of the batch size: a patch's bits must not depend
+// on the batch it is in): images of fewer than four 16x8-pixel tiles split their input channels over up to four
+// work items per tile (4 / tiles per image), each with an even run of >= 4 chunks.  (8 / tiles per image was
+// measured too: at 64 images per batch the second doubling only adds folds and partial-sum traffic.)
+extern "C" int dsic_wino_bf16_ksplit(int H, int W, int Cin) {
+  if (H <= 0 || W <= 0 || Cin < 64 || Cin % 32) return 1;
+  const int t_img = ceil_div(W, 16) * ceil_div(H, 8);
+  int S = t_img >= 4 ? 1 : 4 / t_img;
+  const int nchunks = Cin / wb::CK;
+  while (S > 1 && (nchunks % S || nchunks / S < 4 || (nchunks / S) % 2)) S >>= 1;
+  return S;
+}
+
+extern "C" int dsic_conv3x3_wino_bf16_splitk_nhwc(const float* in, const void* u_planes, const float* bias,
+                                                  const float* beta, const float* gamma, float* out, int B, int H,
+                                                  int W, int Cin, int Cout, int act, int s2d_out, int s2d_in,
+                                                  int out_cstride, int out_coff, int ksplit, float* partials,
+                                                  void* ticket, void* stream) {
+  DSIC_REQUIRE(in && u_planes && bias && out && ticket && partials, "conv3x3_wino_bf16_splitk: null pointer");
+  DSIC_REQUIRE(B > 0 && H > 0 && W > 0, "conv3x3_wino_bf16_splitk: empty tensor");
+  DSIC_REQUIRE(Cin >= 64 && Cin % 32 == 0, "conv3x3_wino_bf16_splitk: Cin=%d must be a multiple of 32, >= 64", Cin);
+  DSIC_REQUIRE(Cout > 0 && Cout % 4 == 0 && Cout <= 128, "conv3x3_wino_bf16_splitk: Cout=%d must be a multiple of 4, <= 128", Cout);
+  DSIC_REQUIRE(act >= 0 && act <= 3, "conv3x3_wino_bf16_splitk: act=%d", act);
+  DSIC_REQUIRE(!(act == DSIC_ACT_GDN || act == DSIC_ACT_IGDN) || (beta && gamma), "conv3x3_wino_bf16_splitk: GDN needs beta and gamma");
+  DSIC_REQUIRE(!s2d_out || (H % 2 == 0 && W % 2 == 0), "conv3x3_wino_bf16_splitk: space-to-depth output needs even H and W");
+  DSIC_REQUIRE(!s2d_in || Cin % 128 == 0, "conv3x3_wino_bf16_splitk: space-to-depth input needs Cin = 4*Cs with Cs %% 32 == 0");
+  DSIC_REQUIRE(ksplit >= 2, "conv3x3_wino_bf16_splitk: ksplit=%d", ksplit);
+  wb::Args a{};
+  a.in = in; a.u = u_planes; a.bias = nullptr; a.beta = nullptr; a.gamma = nullptr; a.out = partials;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.CoutP = round_up(Cout, 32); a.act = DSIC_ACT_NONE;
+  a.s2d = s2d_out; a.s2d_in = s2d_in ? 1 : 0;
+  a.ostride = out_cstride; a.ooff = out_coff;
+  a.ticket = (unsigned long long*)ticket;
+  a.nphase = 1; a.u_phase_bytes = dsic_wino_bf16_weight_bytes(Cout, Cin);
+  a.ksplit = ksplit;
+  const int ostride = out_cstride > 0 ? out_cstride : Cout;
+  a.part_stride = (int64_t)B * H * W * ostride;
+  const int rc = wb_launch(a, (hipStream_t)stream);
+  if (rc != DSIC_OK) return rc;
+  // the space-to-depth output is a [B, H/2, W/2, 4*Cout] tensor: channel of the bias = index mod Cout
+  const int64_t npix = s2d_out ? (int64_t)B * (H / 2) * (W / 2) : (int64_t)B * H * W;
+  const int C = s2d_out ? 4 * Cout : Cout, rstride = s2d_out ? 4 * Cout : ostride;
+  const int64_t nthreads = npix * (C / 4);
+  const dim3 grid((unsigned)((nthreads + 255) / 256)), block(256);
+#define WB_REDUCE(A)                                                                                               \
+  hipLaunchKernelGGL((wb::splitk_reduce_kernel<A>), grid, block, 0, (hipStream_t)stream, (const float*)partials, ksplit, \
+                     a.part_stride, out, npix, C, Cout, rstride, out_coff, bias, beta, gamma)
+  if (act == DSIC_ACT_GDN) WB_REDUCE(DSIC_ACT_GDN);
+  else if (act == DSIC_ACT_IGDN) WB_REDUCE(DSIC_ACT_IGDN);
+  else if (act == DSIC_ACT_RELU) WB_REDUCE(DSIC_ACT_RELU);
+  else WB_REDUCE(DSIC_ACT_NONE);
+#undef WB_REDUCE
+  return check_launch("conv3x3_wino_bf16_splitk");
 }
 
 extern "C" int dsic_conv_transpose2d_wino_bf16_nhwc(const float* in, const void* u_planes4, const float* bias,

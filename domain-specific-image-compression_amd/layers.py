@@ -100,6 +100,10 @@ class Conv2d(_ConvBase):
         super().__init__()
         self.in_channels, self.out_channels = in_ch, out_ch
         self.kernel_size, self.stride = k, stride
+        # layers on few tiles per image may share a tile's input channels between workgroups (ops.WINO_SPLITK);
+        # HyperAnalysis switches it off: its launches run on the side stream, where every extra launch waits for
+        # compute units at a kernel boundary of the main stream
+        self.split_k = True
         w = torch.empty(out_ch, in_ch, k, k)
         nn.init.kaiming_uniform_(w, a=math.sqrt(5))
         bound = 1.0 / math.sqrt(in_ch * k * k)
@@ -170,7 +174,7 @@ class Conv2d(_ConvBase):
             for lo, hi, u, bias in self.packed_wino_slices():
                 ops.conv3x3_wino_nhwc(x, u, bias, hi - lo, act, None if beta is None else beta[lo:hi].contiguous(),
                                       None if gamma is None else gamma[lo:hi].contiguous(), out=out, s2d_in=True,
-                                      out_coff=lo,
+                                      out_coff=lo, split_k=self.split_k,
                                       algo_flops=2.0 * B * H2 * W2 * (hi - lo) * self.in_channels * 25)
             return out
         if (x_is_s2d and DIRECT_5S2 and WINO_BF16 and not s2d_out and self.kernel_size == 5 and self.in_channels >= 64
@@ -184,11 +188,11 @@ class Conv2d(_ConvBase):
         if x_is_s2d:
             B, H2, W2, _ = x.shape
             return ops.conv3x3_wino_nhwc(x, self.packed_wino(), self.bias, self.out_channels, act, beta, gamma,
-                                         s2d_out=s2d_out, s2d_in=True,
+                                         s2d_out=s2d_out, s2d_in=True, split_k=self.split_k,
                                          algo_flops=2.0 * B * H2 * W2 * self.out_channels * self.in_channels * 25)
         if self.use_winograd and x.shape[-1] == self.in_channels:
             return ops.conv3x3_wino_nhwc(x, self.packed_wino(), self.bias, self.out_channels, act, beta, gamma,
-                                         s2d_out=s2d_out)
+                                         s2d_out=s2d_out, split_k=self.split_k)
         assert not s2d_out
         return ops.conv2d_nhwc(x, self.packed(), self.bias, self.out_channels, self.kernel_size,
                                self.stride, act, beta, gamma, cin_real=self.in_channels)
@@ -432,6 +436,9 @@ class HyperAnalysis(nn.Module):
             conv(N, N, 5, 2), nn.ReLU(inplace=True),
             conv(N, N, 5, 2),
         )
+        for m in self.h_a:
+            if isinstance(m, Conv2d):
+                m.split_k = False
 
     def forward_nhwc(self, y, taps=None):
         return self.h_a.forward_nhwc(y, taps)

@@ -46,6 +46,9 @@ SIGNATURES = {
     "dsic_split_wino_weight_bf16": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "dsic_conv3x3_wino_bf16_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                             c_int, c_int, c_int, _P, _P]),
+    "dsic_wino_bf16_ksplit": (c_int, [c_int, c_int, c_int]),
+    "dsic_conv3x3_wino_bf16_splitk_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                   c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "dsic_conv_transpose2d_wino_bf16_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
                                                      _P, _P]),
     "dsic_conv5s2_bf16_weight_bytes": (c_int64, [c_int, c_int]),

@@ -6,6 +6,7 @@ function forwards raw pointers to libdsic_hip.so.
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -30,6 +31,9 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
         raise TypeError(f"{name}: expected float32, got {t.dtype}")
     return t.contiguous()
 
+
+# DSIC_WINO_SPLITK=0: never share a tile's input channels between workgroups (dsic_wino_bf16_ksplit decides otherwise)
+WINO_SPLITK = os.environ.get("DSIC_WINO_SPLITK", "1") != "0"
 
 # Optional per-launch timer (bench.py): object with .record(tag, flops, launch)
 # where launch() enqueues the kernel on the current stream.
@@ -249,7 +253,7 @@ def depth_to_space(x_s2d):
 
 
 def conv3x3_wino_nhwc(x, u_packed, bias, Cout, act=ACT_NONE, beta=None, gamma=None, out=None, s2d_out=False,
-                      algo_flops=None, s2d_in=False, out_coff=0):
+                      algo_flops=None, s2d_in=False, out_coff=0, split_k=True):
     """conv(Cin,Cout,3,1) + fused activation by Winograd F(2x2,3x3) on NHWC activations.
 
     s2d_out: write [B,H/2,W/2,4*Cout] (space-to-depth) for a following 5x5/s2 layer."""
@@ -262,6 +266,18 @@ def conv3x3_wino_nhwc(x, u_packed, bias, Cout, act=ACT_NONE, beta=None, gamma=No
     wino_tiles = B * (-(-H // 8)) * (-(-W // 16)) * 32          # 2x2-output tiles incl. border padding
     if u_packed.dtype == torch.uint8:                            # bf16 planes: split-bf16 kernel
         nprod = 3 if wino_bf16_planes() == 2 else 6
+        ksplit = L.dsic_wino_bf16_ksplit(H, W, Cin) if (WINO_SPLITK and split_k) else 1
+        if ksplit > 1:
+            # few tiles per image: the input channels of a tile are shared by `ksplit` work items
+            partials = torch.empty((ksplit,) + tuple(out.shape), dtype=torch.float32, device=x.device)
+            _timed("conv_wino_bf16_kernel<1>" if s2d_in else "conv_wino_bf16_kernel<0>",
+                   algo_flops if algo_flops is not None else 2.0 * B * H * W * Cout * Cin * 9,
+                   lambda: _lib.check(L.dsic_conv3x3_wino_bf16_splitk_nhwc(
+                       _p(x), _p(u_packed), _p(bias), _p(beta), _p(gamma), _p(out), B, H, W, Cin, Cout, act,
+                       int(bool(s2d_out)), int(bool(s2d_in)), 0 if s2d_out else int(out.shape[-1]), int(out_coff),
+                       ksplit, _p(partials), _p(_ticket(x.device)), _stream()), "conv3x3_wino_bf16_splitk_nhwc"),
+                   exec_flops=2.0 * nprod * wino_tiles * (12.25 if s2d_in else 16) * Cin * round_up(Cout, 32))
+            return out
         _timed("conv_wino_bf16_kernel<1>" if s2d_in else "conv_wino_bf16_kernel<0>",
                algo_flops if algo_flops is not None else 2.0 * B * H * W * Cout * Cin * 9,
                lambda: _lib.check(L.dsic_conv3x3_wino_bf16_nhwc(_p(x), _p(u_packed), _p(bias), _p(beta), _p(gamma),

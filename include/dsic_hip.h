@@ -156,6 +156,19 @@ int dsic_conv3x3_wino_bf16_nhwc(const float* in, const void* u_planes,
                                 const float* gamma, float* out, int B, int H, int W,
                                 int Cin, int Cout, int act, int s2d_out, int s2d_in,
                                 int out_cstride, int out_coff, void* ticket, void* stream);
+/* Split-K for layers whose images hold fewer than four 16x8-pixel tiles (g_a.10/12/14, h_a.*: layers.py:66-72,
+ * 108-112 on 16x16 .. 4x4 latents), where a workgroup would otherwise walk all Cin/16 chunks of a tile alone:
+ * dsic_wino_bf16_ksplit(H, W, Cin) -> S (a function of the layer geometry only, 1 = do not split);
+ * dsic_conv3x3_wino_bf16_splitk_nhwc = dsic_conv3x3_wino_bf16_nhwc with the input channels of every tile
+ * shared by S work items, whose partial sums (partials: S buffers of the size of `out`, caller-owned) are
+ * added in fixed order, biased and activated by a second launch. */
+int dsic_wino_bf16_ksplit(int H, int W, int Cin);
+int dsic_conv3x3_wino_bf16_splitk_nhwc(const float* in, const void* u_planes,
+                                       const float* bias, const float* beta,
+                                       const float* gamma, float* out, int B, int H, int W,
+                                       int Cin, int Cout, int act, int s2d_out, int s2d_in,
+                                       int out_cstride, int out_coff, int ksplit,
+                                       float* partials, void* ticket, void* stream);
 int dsic_conv_transpose2d_wino_bf16_nhwc(const float* in, const void* u_planes4,
                                          const float* bias, const float* beta,
                                          const float* gamma, float* out, int B,

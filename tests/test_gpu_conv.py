@@ -376,3 +376,53 @@ def test_conv5x5_stride2_direct_split_bf16(ops, B, Cs, Cout, H, W, act):
     y2 = ops.conv5s2_bf16_nhwc(xs, ops.pack_conv5s2_bf16_weight(w.cuda()), b.cuda(), Cout, code,
                                (beta_p ** 2 - 2 ** -18).cuda(), (gam_p ** 2 - 2 ** -18).cuda())
     assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,act,s2d_in,s2d_out", [
+    (5, 128, 128, 16, 16, "gdn", False, True),     # g_a.12: 2 tiles per image -> 2 work items per tile, s2d store
+    (3, 512, 128, 8, 8, "none", True, False),      # g_a.14 slice / h_a: 1 tile per image -> 4 work items
+    (70, 512, 128, 16, 16, "gdn", True, False),    # g_a.10 shape, more work items than workgroups
+    (2, 192, 128, 16, 16, "relu", False, False),   # h_a.0: 12 chunks -> runs of 6
+    (1, 128, 64, 6, 10, "igdn", False, False),
+])
+def test_winograd_split_k_equals_unsplit_sums(ops, B, Cin, Cout, H, W, act, s2d_in, s2d_out):
+    """Layers with fewer than four tiles per image share a tile's input channels between work items
+    (dsic_wino_bf16_ksplit) and add the partial sums in a second launch: same result as the unsplit kernel up
+    to the fp32 rounding of the regrouped sum, same addressing (space-to-depth store, channel slices)."""
+    from dsic_amd import lib, ops as OPS
+    S = lib.load().dsic_wino_bf16_ksplit(H, W, Cin)
+    assert S > 1 and (Cin // 16) % S == 0
+    x = _rand((B, H, W, Cin), 91, 2.0).cuda()
+    if s2d_in:
+        w = _rand((Cout, Cin // 4, 5, 5), 92, (Cin // 4 * 25) ** -0.5 * 2).cuda()
+        u = ops.split_wino_weight_bf16(ops.pack_wino_s2_weight(w), Cout, Cin, 1)
+    else:
+        w = _rand((Cout, Cin, 3, 3), 92, (Cin * 9) ** -0.5 * 2).cuda()
+        u = ops.split_wino_weight_bf16(ops.pack_wino_weight(w), Cout, Cin, 1)
+    b = _rand((Cout,), 93, 0.5).cuda()
+    beta = (0.5 + torch.rand(Cout, generator=torch.Generator().manual_seed(4))).cuda()
+    gamma = (0.02 + 0.28 * torch.rand(Cout, generator=torch.Generator().manual_seed(5))).cuda()
+    code = {"none": ops.ACT_NONE, "gdn": ops.ACT_GDN, "igdn": ops.ACT_IGDN, "relu": ops.ACT_RELU}[act]
+    saved = OPS.WINO_SPLITK
+    try:
+        OPS.WINO_SPLITK = False
+        ref = ops.conv3x3_wino_nhwc(x, u, b, Cout, code, beta, gamma, s2d_in=s2d_in, s2d_out=s2d_out)
+        OPS.WINO_SPLITK = True
+        got = ops.conv3x3_wino_nhwc(x, u, b, Cout, code, beta, gamma, s2d_in=s2d_in, s2d_out=s2d_out)
+        again = ops.conv3x3_wino_nhwc(x, u, b, Cout, code, beta, gamma, s2d_in=s2d_in, s2d_out=s2d_out)
+        # a Cout slice of a wider tensor: the partial buffers use the same stride and offset
+        wide = torch.full((B, H, W, Cout + 64), -7.0, device="cuda")
+        if not s2d_out:
+            ops.conv3x3_wino_nhwc(x, u, b, Cout, code, beta, gamma, s2d_in=s2d_in, out=wide, out_coff=64)
+    finally:
+        OPS.WINO_SPLITK = saved
+    assert torch.equal(got, again)                                  # fixed summation order
+    assert got.shape == ref.shape
+    err = float((got - ref).abs().max())
+    assert 0 < err <= 4e-6 * float(ref.abs().max()), err            # regrouped fp32 sums, nothing else
+    if not s2d_out:
+        assert torch.equal(wide[..., 64:], got) and bool((wide[..., :64] == -7.0).all())
+    # one image alone takes the same split: batch invariance
+    OPS.WINO_SPLITK = True
+    solo = ops.conv3x3_wino_nhwc(x[B - 1:].contiguous(), u, b, Cout, code, beta, gamma, s2d_in=s2d_in, s2d_out=s2d_out)
+    assert torch.equal(solo[0], got[B - 1])
