@@ -25,7 +25,7 @@
 //     (Winograd tile, channel quad, half of the positions) then reads three rows of its 4x4 patch
 //     from there, applies B^T d B in fp32, splits into the bf16 planes and stores them into the V
 //     buffer the MFMA waves are not reading.
-// Tile hand-out, the fold through LDS and the fused epilogue are those of conv_wino.hip.
+// Tile hand-out, the fold through LDS and the fused epilogue follow conv_wino.hip.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -148,6 +148,37 @@ __device__ __forceinline__ float bf16_hi(unsigned pk) { return __builtin_bit_cas
 struct Tile {
   int item, tx, ty, n, ks;
 };
+
+// Which 8 of the 16 Winograd positions (xi, nu) an MFMA wave of position half ph owns: the checkerboard
+// (xi + nu) & 1 == ph.  A structurally zero row (xi) or column (nu) of a chunk - space-to-depth blocks, ConvTranspose
+// phases - then costs both halves two positions each (a split by rows left one half with 8 live positions beside 4).
+// 4 bits per step pi: xi*4 + nu, positions that can be structurally zero last (MODE 1: xi = 3 / nu = 3, MODE 2:
+// xi = 0 / nu = 0), so that the two fragments prefetched across a chunk boundary are always live.
+template <int MODE, int PH>
+struct PosTab {
+  static constexpr unsigned value = MODE == 2 ? (PH ? 0xC431EB96u : 0x820FDA75u) : (PH ? 0xECB39641u : 0xFD7A8520u);
+};
+
+// one output (i, j) of A^T M A restricted to the 8 positions of half PH: sum of +-acc[pi]
+template <int MODE, int PH, int I, int J>
+__device__ __forceinline__ floatx16 fold_partial(const floatx16 (&acc)[8]) {
+  constexpr int AT[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
+  floatx16 s;
+  bool first = true;
+#pragma unroll
+  for (int pi = 0; pi < 8; ++pi) {
+    const unsigned g = (PosTab<MODE, PH>::value >> (4 * pi)) & 15u;
+    const int coef = AT[I][g >> 2] * AT[J][g & 3];
+    if (coef == 0) continue;
+    if (first) {
+      s = coef > 0 ? acc[pi] : -acc[pi];
+      first = false;
+    } else {
+      s = coef > 0 ? s + acc[pi] : s - acc[pi];
+    }
+  }
+  return s;
+}
 
 // SPLITK is a template parameter: the unsplit kernels keep their register allocation (with the work item's chunk
 // offset as run-time state the 3x3 kernel spilled 20 more SGPRs into its loops and ran 20 % slower).
@@ -463,15 +494,13 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
   const int nt = wave & 3, ph = wave >> 2;
   const bool nvalid = nt * 32 < a.CoutP;
   constexpr bool ZSKIP = MODE != 0;
-  constexpr int PDIR = MODE == 2 ? -1 : 1;
   // U stream: [pos][chunk][plane][CoutP][16 bf16]; a fragment = 64 lanes x 16 bytes
   const unsigned plane_b = (unsigned)a.CoutP * 32u;
   const unsigned chunk_b = plane_b * (unsigned)P;
   const unsigned pos_b = chunk_b * (unsigned)tchunks;
   const unsigned ulane = (unsigned)((((nvalid ? nt : 0) * 32 + l31) * 2 + h) * 16);
-  auto pos_of = [](int pi) { return PDIR > 0 ? pi : 7 - pi; };
   // V reads: row l31 of position ph*8+p, k-block h (swizzled)
-  const int aread = (ph * 8) * POSB + l31 * ROWB + ((h ^ ((l31 >> 3) & 1)) << 4);
+  const int aread = l31 * ROWB + ((h ^ ((l31 >> 3) & 1)) << 4);
   float pbias = 0.f, pbeta = 1.f, pgamma = 0.f;
   {
     const int col = nt * 32 + l31;
@@ -483,6 +512,11 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
       }
     }
   }
+  // The loop is compiled once per position half: the positions of a step are then compile-time LDS offsets.
+  auto mfma_waves = [&](auto ph_tag) {
+  constexpr int PH = decltype(ph_tag)::value;
+  constexpr unsigned ptab = PosTab<MODE, PH>::value;
+  auto pos_of = [](int pi) { return (int)((ptab >> (4 * pi)) & 15u); };   // global position xi*4 + nu of step pi
   floatx16 acc[8];
   bf16x8 Bq[RING][P];
   __syncthreads();  // P0
@@ -498,7 +532,7 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
   };
   unsigned soff_phase = soff_item(cur);
   auto soff_of = [&](unsigned phase_off, int chunk, int pi) {
-    return phase_off + (unsigned)(ph * 8 + pos_of(pi)) * pos_b + (unsigned)chunk * chunk_b;
+    return phase_off + (unsigned)pos_of(pi) * pos_b + (unsigned)chunk * chunk_b;
   };
   auto fetch = [&](bf16x8 (&dst)[P], unsigned so) {
     if (WB_ABL & 1) so = 0;
@@ -531,7 +565,7 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
       }
       auto is_zero = [&](int pi) {
         const int p = pos_of(pi);
-        const unsigned xi = (unsigned)(ph * 2 + (p >> 2)), nu = (unsigned)(p & 3);
+        const unsigned xi = (unsigned)(p >> 2), nu = (unsigned)(p & 3);
         return xi == zero_xi || nu == zero_nu;
       };
       const unsigned char* vb = lds_raw + (chunk & 1) * VBUFB + aread;
@@ -552,7 +586,7 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
 #endif
 #pragma unroll
       for (int pi = 0; pi < 8; ++pi) {
-        const int p0 = pos_of(pi);
+        const int p0 = pi;   // accumulators are indexed by step
         const bool live = !ZSKIP || !is_zero(pi);  // wave-uniform
 #if WB_ADOUBLE
         if (pi + 1 < 8) {
@@ -607,18 +641,24 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
     if (WB_ABL & 8) {
       __syncthreads();
     } else {
-      float* yown = yreg + ((4 * (2 * ph) + nt) * 32 + 4 * h) * WP + l31;
-      float* yoth = yreg + ((4 * (2 * (ph ^ 1)) + nt) * 32 + 4 * h) * WP + l31;
+      float* yown = yreg + ((4 * (2 * PH) + nt) * 32 + 4 * h) * WP + l31;
+      float* yoth = yreg + ((4 * (2 * (PH ^ 1)) + nt) * 32 + 4 * h) * WP + l31;
+      // Y = A^T M A: this wave's 8 positions contribute to all four outputs (i, j) of a tile.  It owns output
+      // row i = ph (written to its half of the output region) and sends its share of row ph^1 to the other
+      // position half, which finishes that row after the barrier.
       floatx16 send[2];
+      {
+        const floatx16 own = fold_partial<MODE, PH, PH, 0>(acc);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const floatx16 na = j == 0 ? (acc[0] + acc[1]) + acc[2] : sub16(sub16(acc[1], acc[2]), acc[3]);
-        const floatx16 nb = j == 0 ? (acc[4] + acc[5]) + acc[6] : sub16(sub16(acc[5], acc[6]), acc[7]);
-        const floatx16 own = ph == 0 ? na + nb : -(na + nb);
-        send[j] = ph == 0 ? nb : na;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) yown[(4 * j * 32 + (e & 3) + 8 * (e >> 2)) * WP] = own[e];
+        for (int e = 0; e < 16; ++e) yown[((e & 3) + 8 * (e >> 2)) * WP] = own[e];
       }
+      {
+        const floatx16 own = fold_partial<MODE, PH, PH, 1>(acc);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) yown[(4 * 32 + (e & 3) + 8 * (e >> 2)) * WP] = own[e];
+      }
+      send[0] = fold_partial<MODE, PH, PH ^ 1, 0>(acc);
+      send[1] = fold_partial<MODE, PH, PH ^ 1, 1>(acc);
       WSTAMP(0, 61);
       __syncthreads();  // E1
       auto finish_rows = [&](auto act_tag) {
@@ -659,6 +699,11 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
     cur = nxt;
     s_nxt = s_nxt == 2 ? 0 : s_nxt + 1;
   }
+  };
+  if (ph == 0)
+    mfma_waves(std::integral_constant<int, 0>{});
+  else
+    mfma_waves(std::integral_constant<int, 1>{});
 }
 
 // fp32 transformed weights [16][Cin/8][CoutP][8] (dsic_pack_wino_*_weight, one block per phase) ->
