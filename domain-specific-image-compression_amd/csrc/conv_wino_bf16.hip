@@ -40,7 +40,7 @@
 #endif
 #ifndef WB_ABL
 #define WB_ABL 0     // compile-time ablations (diagnostic, wrong results): 1 U from one hot line, 2 no input loads,
-#endif               // 4 no transform / V stores, 8 no fold, 16 no MFMAs.  (A run-time switch would put a branch
+#endif               // 4 no transform / V stores, 8 no fold, 16 no MFMAs, 32 half of the MFMA waves' V reads.  (A run-time switch would put a branch
                      // around every MFMA cluster and cost the loop its scheduling.)
 #ifndef WB_ADOUBLE
 #define WB_ADOUBLE 0
@@ -50,6 +50,9 @@
 #endif
 #ifndef WB_STAMP_TILE
 #define WB_STAMP_TILE 8
+#endif
+#ifndef WB_STAMP_C0
+#define WB_STAMP_C0 0   // first chunk that gets stamps (20 chunks of the MFMA wave, 15 of the helper wave fit)
 #endif
 
 namespace dsic {
@@ -114,8 +117,13 @@ __device__ long long wb_stamps[256 * 128];
       ((long long*)(lds_raw + STAMPOFF))[((w) == 0 ? 0 : 64) + (i)] = __builtin_amdgcn_s_memtime(); \
     __builtin_amdgcn_sched_barrier(0);                                                             \
   } while (0)
+#define WSTAMPC(w, i, lim)                 \
+  do {                                     \
+    if ((i) >= 0 && (i) < (lim)) WSTAMP(w, i); \
+  } while (0)
 #else
 #define WSTAMP(w, i)
+#define WSTAMPC(w, i, lim)
 #endif
 
 __device__ __forceinline__ floatx2 pk_sub(floatx2 a, floatx2 b) {
@@ -432,17 +440,17 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
       // phase issues the same memory operations whatever the tile: with no next tile the aim points
       // nowhere (loads return 0 without traffic) and the staged / committed chunks are never read.
       auto phase = [&](floatx4 (&R)[3], int c) {
-        WSTAMP(8, 4 * c);
+        WSTAMPC(8, 4 * (c - WB_STAMP_C0), 64);
         stage(R, c & 1);                                                 // window of chunk c+2
-        WSTAMP(8, 4 * c + 1);
+        WSTAMPC(8, 4 * (c - WB_STAMP_C0) + 1, 64);
         {
           unsigned zxi, znu;                                             // target c+1
           if (c + 1 < nchunks) zero_of(cur, c + 1, zxi, znu); else zero_of(nxt, 0, zxi, znu);
           commit((c + 1) & 1, (c + 1) & 1, zxi, znu);
         }
-        WSTAMP(8, 4 * c + 2);
+        WSTAMPC(8, 4 * (c - WB_STAMP_C0) + 2, 64);
         __syncthreads();  // B_c
-        WSTAMP(8, 4 * c + 3);
+        WSTAMPC(8, 4 * (c - WB_STAMP_C0) + 3, 64);
         const int k4 = c + 4;
         if (k4 == nchunks) {   // phase n-4: from here on every load is for the next tile
           if (more) aim(am, nxt); else aim_nowhere(am);
@@ -552,7 +560,7 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
     auto chunk_body = [&](auto first_tag, int chunk) {
       constexpr bool FIRST = decltype(first_tag)::value;
       const bool last = chunk + 1 == nchunks;
-      WSTAMP(0, 3 * chunk);
+      WSTAMPC(0, 3 * (chunk - WB_STAMP_C0), 60);
       unsigned zero_xi = 4, zero_nu = 4;
       if (MODE == 1) {
         const int blk = (cur.ks * nchunks + chunk) / (tchunks >> 2);
@@ -611,7 +619,7 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
           for (int e = 0; e < 16; ++e) acc[p0][e] = 0.f;
         }
 #if !WB_ADOUBLE
-        if (pi + 1 < 8) {
+        if (pi + 1 < 8 && !((WB_ABL & 32) && (pi & 1) == 0)) {   // ablation 32: every second V read dropped
 #pragma unroll
           for (int q = 0; q < P; ++q) Aq1[q] = *(const bf16x8*)(vb + pos_of(pi + 1) * POSB + q * PLANEB);
         }
@@ -628,9 +636,9 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
         }
       }
 #undef AQ
-      WSTAMP(0, 3 * chunk + 1);
+      WSTAMPC(0, 3 * (chunk - WB_STAMP_C0) + 1, 60);
       __syncthreads();  // B_chunk
-      WSTAMP(0, 3 * chunk + 2);
+      WSTAMPC(0, 3 * (chunk - WB_STAMP_C0) + 2, 60);
     };
     chunk_body(std::true_type{}, 0);
     for (int chunk = 1; chunk < nchunks; ++chunk) chunk_body(std::false_type{}, chunk);

@@ -29,12 +29,13 @@ assert L.dsic_debug_wb_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
 s = buf.reshape(256, 128).astype(np.float64)
 m, hlp = s[:, :64], s[:, 64:]
 d = lambda arr, a, b: np.median(arr[:, b] - arr[:, a])
-nc = min(n, 20)
+C0 = int(os.environ.get("C0", "0"))          # build with -DWB_STAMP_C0=<C0> to see the chunks from C0 on
+nc = min(n - C0, 20)
 print("MFMA wave 0:  chunk: mfma-phase | barrier wait | gap")
 for c in range(nc):
-    print(f"  {c:2d}: {d(m, 3*c, 3*c+1):7.0f} | {d(m, 3*c+1, 3*c+2):7.0f} | {d(m, 3*c+2, 3*c+3) if c + 1 < nc else 0:7.0f}")
+    print(f"  {c + C0:2d}: {d(m, 3*c, 3*c+1):7.0f} | {d(m, 3*c+1, 3*c+2):7.0f} | {d(m, 3*c+2, 3*c+3) if c + 1 < nc else 0:7.0f}")
 print(f"  fold->E1 {d(m, 60, 61):7.0f}  finish {d(m, 61, 62):7.0f}  E2 wait {d(m, 62, 63):7.0f}")
 print("helper wave 8: phase: stage (waits for the window loads) | commit | barrier wait | issue+stores+gap")
 for c in range(min(nc, 15)):
-    print(f"  {c:2d}: {d(hlp, 4*c, 4*c+1):7.0f} | {d(hlp, 4*c+1, 4*c+2):7.0f} | {d(hlp, 4*c+2, 4*c+3):7.0f} | {d(hlp, 4*c+3, 4*c+4) if c + 1 < min(nc, 15) else 0:7.0f}")
+    print(f"  {c + C0:2d}: {d(hlp, 4*c, 4*c+1):7.0f} | {d(hlp, 4*c+1, 4*c+2):7.0f} | {d(hlp, 4*c+2, 4*c+3):7.0f} | {d(hlp, 4*c+3, 4*c+4) if c + 1 < min(nc, 15) else 0:7.0f}")
 print(f"per-chunk period (MFMA wave): {d(m, 0, 3*(nc-1)) / (nc-1):.0f} cycles")
