@@ -70,6 +70,50 @@ __global__ __launch_bounds__(256) void support_kernel(const float* __restrict__ 
   }
 }
 
+// dm::finish_table with the 64 lanes of a wave: everything that is element-wise (pmf, clamp, divide, scaling,
+// truncation, spreading) runs one entry per lane; the two order-sensitive reductions keep the serial order of the
+// host function - the float32 sum (torch's cascade) is evaluated by every lane alike, the float64 running sum walks
+// the entries through v_readlane.  Same operations on the same operands: the tables are bit-identical to
+// dm::finish_table (tests/test_gpu_entropy.py compares them with the host entry point).  F[0..L] is overwritten
+// with the rounded prefixes.
+__device__ __forceinline__ void finish_table_wave(float* F, int L, uint16_t* out, float* pmf, int lane) {
+  for (int k = lane; k < L; k += 64) {
+    float p = F[k + 1] - F[k];
+    if (p < 1e-12f) p = 1e-12f;
+    pmf[k] = p;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  const float total = dm::sum_f32_torch(pmf, L);
+  double cum = 0.0;
+  for (int base = 0; base < L; base += 64) {
+    const int k = base + lane;
+    const float q = k < L ? pmf[k] / total : 0.0f;
+    const int n = L - base < 64 ? L - base : 64;
+    float mine = 0.0f;
+    for (int j = 0; j < n; ++j) {
+      const float qj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q), j));
+      cum = cum + (double)qj;
+      float c = (float)cum;
+      if (base + j == L - 1 && c < 1.0f) c = 1.0f;
+      if (j == lane) mine = c;
+    }
+    if (k < L) F[k] = mine;       // prefix that includes entry k
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  for (int k = lane; k < L; k += 64) {
+    uint32_t u16 = 0;
+    if (k > 0) {
+      float sc = F[k - 1] * 65535.0f;
+      if (sc < 0.0f) sc = 0.0f;
+      if (sc > 65535.0f) sc = 65535.0f;
+      u16 = (uint32_t)sc;
+    }
+    out[k] = (uint16_t)((u16 * (uint32_t)(65536 - L)) / 65535u + (uint32_t)k);   // < 2^32: one 32-bit division
+  }
+}
+
 // One wave per table.  sigma/nu indexed [b*sb + c] (sb = 0 for the image-independent z prior).
 template <bool STUDENT>
 __global__ __launch_bounds__(256) void tables_kernel(const float* __restrict__ sigma,
@@ -95,7 +139,7 @@ __global__ __launch_bounds__(256) void tables_kernel(const float* __restrict__ s
     F[k] = STUDENT ? dm::table_cdf_student(smin, k, sg, nv) : dm::table_cdf_gauss(smin, k, sg);
   __builtin_amdgcn_s_waitcnt(0xc07f);
   __builtin_amdgcn_wave_barrier();
-  if (lane == 0) dm::finish_table(F, L, tables + ((size_t)b * C + c) * Lmax, pmf, nullptr);
+  finish_table_wave(F, L, tables + ((size_t)b * C + c) * Lmax, pmf, lane);
 }
 
 // Range encoder, one wave per (image, stream): stream ids 0..B-1 = y strings, B..2B-1 = z strings (which 0: z string,

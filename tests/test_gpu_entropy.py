@@ -185,6 +185,13 @@ def test_decoder_with_wide_supports(spread):
     assert int(c["err"].item()) == 0
     lens = c["lengths"].cpu().numpy()
     raw = c["bytes"].cpu().numpy()
+    # the wave-parallel table finish (several 64-entry rounds per table here) equals the serial host order
+    meta = c["meta"].cpu().numpy()
+    ty, tz = c["tab_y"].cpu().numpy().reshape(B, M, -1), c["tab_z"].cpu().numpy().reshape(B, N, -1)
+    for b in range(B):
+        Ly, Lz = int(meta[b, 1]), int(meta[b, 3])
+        assert np.array_equal(ty[b, :, :Ly], E.tables_student(sy[b], ny[b], int(meta[b, 0]), Ly))
+        assert np.array_equal(tz[b, :, :Lz], E.tables_gauss(sz, int(meta[b, 2]), Lz))
     for b in range(B):
         assert raw[b, :lens[b, 0]].tobytes() == want["strings"][b][0]
         assert raw[b, c["cap_z"]:c["cap_z"] + lens[b, 1]].tobytes() == want["strings"][b][1]
