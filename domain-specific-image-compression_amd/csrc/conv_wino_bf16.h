@@ -1,5 +1,5 @@
-// Shared by conv_wino_bf16.hip (8 MFMA + 4 helper waves) and conv_wino_bf16x.hip (8 waves that do both jobs):
-// launch arguments, the LDS layout, the position tables and the fold of the split-bf16 Winograd kernels.
+// Launch arguments, LDS layout, position tables and the fold of the split-bf16 Winograd kernel (conv_wino_bf16.hip).
+// (A header since the fused-role experiment of round 2, commit 5f523cb: a second kernel built on the same pieces.)
 #pragma once
 #include <stdlib.h>
 

@@ -642,8 +642,6 @@ extern "C" int dsic_split_wino_weight_bf16(const float* u_f32, void* dst, int Co
   return check_launch("split_wino_weight_bf16");
 }
 
-int dsic_wbx_launch(const wb::Args& a, int grid, hipStream_t st);   // conv_wino_bf16x.hip
-
 static int wb_launch(wb::Args& a, hipStream_t st) {
   const int B = a.B, H = a.H, W = a.W;
   a.tiles_x = ceil_div(W, 16);
@@ -691,12 +689,6 @@ static int wb_launch(wb::Args& a, hipStream_t st) {
   }
   const int64_t nwork = (int64_t)a.ntiles * a.ksplit;
   const int grid = nwork < max_grid ? (int)nwork : max_grid;
-  static int fused = -1;   // DSIC_WINO_FUSED=1: the 8-wave kernel whose waves transform and multiply (unsplit layers)
-  if (fused < 0) {
-    const char* f = getenv("DSIC_WINO_FUSED");
-    fused = f && atoi(f) != 0;
-  }
-  if (fused && a.ksplit == 1) return dsic_wbx_launch(a, grid, st);
 #define WB_LAUNCH(M)                                                                                          \
   do {                                                                                                        \
     if (a.nt_out)                                                                                             \
