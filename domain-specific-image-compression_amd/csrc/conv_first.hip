@@ -8,16 +8,36 @@
 // pixel tile in LDS, A operands gathered with one ds_read_b32 per k-step
 // (k = c*9 + ky*3 + kx, the reference weight order), GDN epilogue + LDS
 // transpose + 16-byte stores as in conv_igemm.hip.
+//
+// BF16 = true (the default, DSIC_WINO_BF16 != 0): the contraction runs on v_mfma_f32_32x32x16_bf16 with both operands
+// split into two bf16 planes (hi*hi + hi*mid + mid*hi, fp32 accumulate - the scheme of conv_wino_bf16.hip).  The
+// window is expanded once per workgroup into an im2col tile in LDS, 128 pixels x [hi K' | mid K'] bf16 (K' = K
+// rounded up to 16; pixel records 16 bytes longer than that: conflict-free ds_read_b128), so an A fragment is one
+// 16-byte read per lane and plane, shared by the four waves; the weights are split once per wave into registers.
+// 6 (K = 27) or 9 (K = 36) MFMAs of 32 cycles per 32x32 tile instead of 14 or 18 of 64.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
 
 namespace dsic {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// eight fp32 values -> bf16 planes hi = bf16(v), mid = bf16(v - hi) (round to nearest even)
+__device__ __forceinline__ void first_split8(const floatx8 v, bf16x8& hi, bf16x8& mid) {
+  hi = __builtin_convertvector(v, bf16x8);
+  const floatx8 back = __builtin_convertvector(hi, floatx8);
+  mid = __builtin_convertvector(v - back, bf16x8);
+}
 
 // U8: the image arrives as uint8 HWC (a decoded PNG/JPEG, PIL / numpy layout) and is converted on
 // the fly exactly like torchvision's to_tensor (code/modelv2/modelseval.py:66-67): float(v) / 255.0f.
-template <int C, bool U8 = false>
+template <int C, bool U8 = false, bool BF16 = false>
 __global__ __launch_bounds__(256, 2) void conv_first_kernel(
     const void* __restrict__ xv, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ beta, const float* __restrict__ gamma, float* __restrict__ out, int B,
@@ -30,6 +50,10 @@ __global__ __launch_bounds__(256, 2) void conv_first_kernel(
   constexpr int WIN_FLOATS = C * WH * RS;
   constexpr int EPI_FLOATS = 4 * 32 * EPI_STRIDE;
   __shared__ __attribute__((aligned(16))) float lds[WIN_FLOATS > EPI_FLOATS ? WIN_FLOATS : EPI_FLOATS];
+  constexpr int KB = (K + 15) / 16 * 16;   // bf16 path: K rounded to MFMA k-steps of 16
+  constexpr int NKS = KB / 16;
+  constexpr int PXB = 4 * KB + 16;         // bytes per im2col pixel record: hi[KB] | mid[KB] bf16 + pad
+  __shared__ __attribute__((aligned(16))) unsigned char im2col[BF16 ? 128 * PXB : 16];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -44,26 +68,39 @@ __global__ __launch_bounds__(256, 2) void conv_first_kernel(
   // weights of this wave's 32 output columns: b[s] = Wk[2s+h][col]
   const int col = wave * 32 + l31;
   const bool colok = col < Cout;
-  float b[NS];
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const int k = 2 * s + h;
-    b[s] = (colok && k < K) ? w[(size_t)col * K + k] : 0.f;  // reference layout [Cout][C][3][3]
-  }
-  // per-lane LDS offsets of the A gather
-  int aoff[NS];
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    int k = 2 * s + h;
-    if (k >= K) k = 0;  // padded k-step: weight is zero, any valid address
-    const int c = k / 9, t = k % 9;
-    aoff[s] = (c * WH + t / 3) * RS + t % 3;
-  }
+  float b[BF16 ? 1 : NS];
+  int aoff[BF16 ? 1 : NS];   // per-lane LDS offsets of the A gather
   int abase[4];
+  bf16x8 bhi[BF16 ? NKS : 1], bmid[BF16 ? NKS : 1];   // bf16 path: B fragments, lane (n = l31, k block h)
+  if (BF16) {
 #pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const int r = m * 32 + l31;
-    abase[m] = (r / TW) * RS + r % TW;
+    for (int ks = 0; ks < NKS; ++ks) {
+      floatx8 wv;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = ks * 16 + h * 8 + j;
+        wv[j] = (colok && k < K) ? w[(size_t)col * K + k] : 0.f;
+      }
+      first_split8(wv, bhi[ks], bmid[ks]);
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int k = 2 * s + h;
+      b[s] = (colok && k < K) ? w[(size_t)col * K + k] : 0.f;  // reference layout [Cout][C][3][3]
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      int k = 2 * s + h;
+      if (k >= K) k = 0;  // padded k-step: weight is zero, any valid address
+      const int c = k / 9, t = k % 9;
+      aoff[s] = (c * WH + t / 3) * RS + t % 3;
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int r = m * 32 + l31;
+      abase[m] = (r / TW) * RS + r % TW;
+    }
   }
 
   // stage the window (zero padded)
@@ -93,13 +130,54 @@ __global__ __launch_bounds__(256, 2) void conv_first_kernel(
   for (int m = 0; m < 4; ++m)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+  if (BF16) {
+    // im2col: thread = (pixel, half of the k octets); octet o holds k = 8o .. 8o+7, k = c*9 + ky*3 + kx
+    const int px = tid & 127, half = tid >> 7;   // half is wave-uniform
+    const int pbase = (px / TW) * RS + px % TW;
+    auto build = [&](auto half_tag) {   // the k -> (c, ky, kx) arithmetic folds at compile time
+      constexpr int HALF = decltype(half_tag)::value;
 #pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    float a[4];
+      for (int oo = 0; oo < NKS; ++oo) {
+        const int o = 2 * oo + HALF;
+        floatx8 v;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) a[m] = lds[abase[m] + aoff[s]];
+        for (int j = 0; j < 8; ++j) {
+          const int k = 8 * o + j;
+          const int c = k / 9, t = k % 9;
+          v[j] = k < K ? lds[pbase + (c * WH + t / 3) * RS + t % 3] : 0.f;
+        }
+        bf16x8 vh, vm;
+        first_split8(v, vh, vm);
+        *(bf16x8*)(im2col + px * PXB + o * 16) = vh;
+        *(bf16x8*)(im2col + px * PXB + 2 * KB + o * 16) = vm;
+      }
+    };
+    if (half == 0)
+      build(std::integral_constant<int, 0>{});
+    else
+      build(std::integral_constant<int, 1>{});
+    __syncthreads();
 #pragma unroll
-    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[s], acc[m], 0, 0, 0);
+    for (int m = 0; m < 4; ++m) {
+      const unsigned char* ap = im2col + (m * 32 + l31) * PXB + h * 16;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const bf16x8 ah = *(const bf16x8*)(ap + ks * 32);
+        const bf16x8 am = *(const bf16x8*)(ap + 2 * KB + ks * 32);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bmid[ks], acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bhi[ks], acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bhi[ks], acc[m], 0, 0, 0);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      float a[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) a[m] = lds[abase[m] + aoff[s]];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[s], acc[m], 0, 0, 0);
+    }
   }
   __syncthreads();  // window no longer needed: LDS becomes the transpose scratch
 
@@ -190,14 +268,28 @@ static int conv_first_launch(const void* x, bool u8, const float* w_oihw, const 
   DSIC_REQUIRE((int64_t)tx * ty * B < ((int64_t)1 << 31), "conv_first: grid too large");
   dim3 grid(tx * ty * B), block(256);
   hipStream_t st = (hipStream_t)stream;
-#define DSIC_FIRST(CC, UU)                                                                                        \
-  hipLaunchKernelGGL((conv_first_kernel<CC, UU>), grid, block, 0, st, x, w_oihw, bias, beta, gamma, out_nhwc, B, H, \
-                     W, Cout, act, tx, ty, s2d)
-  if (Cimg == 3) {
-    if (u8) DSIC_FIRST(3, true); else DSIC_FIRST(3, false);
-  } else {
-    if (u8) DSIC_FIRST(4, true); else DSIC_FIRST(4, false);
+  // DSIC_WINO_BF16=0 (the switch that selects the exact-fp32 Winograd kernels) keeps this layer on the fp32-input MFMA
+  static int use_bf16 = -1;
+  if (use_bf16 < 0) {
+    const char* e = getenv("DSIC_WINO_BF16");
+    use_bf16 = (e && e[0] == '0' && e[1] == 0) ? 0 : 1;
   }
+#define DSIC_FIRST(CC, UU, BB)                                                                                        \
+  hipLaunchKernelGGL((conv_first_kernel<CC, UU, BB>), grid, block, 0, st, x, w_oihw, bias, beta, gamma, out_nhwc, B, H, \
+                     W, Cout, act, tx, ty, s2d)
+#define DSIC_FIRST2(CC, UU) \
+  do {                      \
+    if (use_bf16)           \
+      DSIC_FIRST(CC, UU, true); \
+    else                    \
+      DSIC_FIRST(CC, UU, false); \
+  } while (0)
+  if (Cimg == 3) {
+    if (u8) DSIC_FIRST2(3, true); else DSIC_FIRST2(3, false);
+  } else {
+    if (u8) DSIC_FIRST2(4, true); else DSIC_FIRST2(4, false);
+  }
+#undef DSIC_FIRST2
 #undef DSIC_FIRST
   return check_launch("conv_first");
 }

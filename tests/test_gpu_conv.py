@@ -195,7 +195,9 @@ def test_first_layer_kernel_vs_oracle(ops, B, C, Cout, H, W, act):
                             (gam_p ** 2 - 2 ** -18).cuda())
     got = ops.nhwc_to_nchw(y).cpu()
     assert got.shape == ref.shape
-    assert float((got - ref).abs().max()) <= _tol(ref, C * 9) * 4
+    # (the layer runs on split-bf16 MFMAs unless DSIC_WINO_BF16=0: the tolerance class of the other split layers)
+    from dsic_amd import layers as Lm
+    assert float((got - ref).abs().max()) <= _tol(ref, C * 9) * 4 * (4.0 if Lm.WINO_BF16 else 1.0)
 
 
 WINO_CASES = [
