@@ -29,6 +29,11 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
         raise RuntimeError(f"{name}: expected a tensor on the GPU (no CPU fallback), got {t.device}")
     if t.dtype != torch.float32:
         raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    if t.device.index != torch.cuda.current_device():
+        # launches go to the current stream of the current device (_stream): a tensor of another GPU would be
+        # read through the wrong stream, and its kernel attributes are set per device
+        raise RuntimeError(f"{name}: tensor on {t.device}, current device is cuda:{torch.cuda.current_device()} "
+                           "(one process drives one GPU; wrap the call in torch.cuda.device(...))")
     return t.contiguous()
 
 
