@@ -784,12 +784,17 @@ static int wino_launch(WinoArgs& a, hipStream_t st) {
   }
   // persistent: one workgroup per CU.  DSIC_WINO_GRID lowers the count when the launching stream
   // owns fewer CUs (CU-masked streams, dsic_stream_create_masked).
-  static int max_grid = 0;
-  if (max_grid == 0) {
+  // one persistent workgroup per compute unit of THIS device (DSIC_WINO_GRID overrides it for experiments)
+  static int max_grid_dev[64] = {};
+  if (max_grid_dev[dev] == 0) {
     const char* g = getenv("DSIC_WINO_GRID");
-    max_grid = g ? atoi(g) : 256;
-    if (max_grid < 1 || max_grid > 1024) max_grid = 256;
+    int n = g ? atoi(g) : 0;
+    if (n < 1 || n > 1024) {
+      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    }
+    max_grid_dev[dev] = n;
   }
+  const int max_grid = max_grid_dev[dev];
   const int grid = a.ntiles < max_grid ? a.ntiles : max_grid;
   if (a.s2d_in)
     hipLaunchKernelGGL(conv_wino_kernel<1>, dim3(grid), dim3(WTHREADS), WLDS_TOTAL, st, a);

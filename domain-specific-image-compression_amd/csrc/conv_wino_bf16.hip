@@ -681,12 +681,17 @@ static int wb_launch(wb::Args& a, hipStream_t st) {
     }
     attr_set[dev] = true;
   }
-  static int max_grid = 0;
-  if (max_grid == 0) {
+  // one persistent workgroup per compute unit of THIS device (DSIC_WINO_GRID overrides it for experiments)
+  static int max_grid_dev[64] = {};
+  if (max_grid_dev[dev] == 0) {
     const char* g = getenv("DSIC_WINO_GRID");
-    max_grid = g ? atoi(g) : 256;
-    if (max_grid < 1 || max_grid > 1024) max_grid = 256;
+    int n = g ? atoi(g) : 0;
+    if (n < 1 || n > 1024) {
+      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    }
+    max_grid_dev[dev] = n;
   }
+  const int max_grid = max_grid_dev[dev];
   const int64_t nwork = (int64_t)a.ntiles * a.ksplit;
   const int grid = nwork < max_grid ? (int)nwork : max_grid;
 #define WB_LAUNCH(M)                                                                                          \
