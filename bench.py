@@ -24,6 +24,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# The workload uses five HIP streams per process (main, hyperprior branch, two coder streams, RCCL's).  The HIP
+# runtime maps streams onto 4 hardware queues by default; a fifth stream then shares a queue, and the metric
+# all-reduce queued behind a 4.7 ms encoder kernel cost 2 ms per step under torch.distributed.run (6 720 instead
+# of 8 520 patches/s).  Must be set before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
