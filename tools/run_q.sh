@@ -1,17 +1,12 @@
 cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/q; mkdir -p $OUT
-python3 bench.py --no-cpu-baseline > $OUT/c3.json 2>/dev/null
+G=gpurun_out
+python3 bench.py > $G/bench_config3.json 2> $G/bench_config3.err
+python3 bench.py --no-entropy > $G/bench_config2.json 2> $G/bench_config2.err
+python3 bench.py --size 512 --channels 4 --batch 32 --steps 12 --warmup 3 > $G/bench_config5.json 2> $G/bench_config5.err
+DSIC_WINO_BF16=0 python3 bench.py --no-cpu-baseline > $G/bench_config3_fp32kernels.json 2> /dev/null
 python3 - <<PY
 import json
-d=json.load(open("$OUT/c3.json")); print("plain", round(d["value"]), round(d["ms_per_step"],3))
-PY
-python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29555 bench.py --gpus 1 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/t.json
-python3 - <<PY
-import json
-d=json.load(open("$OUT/t.json")); print("torchrun", round(d["value"]), round(d["ms_per_step"],3))
-PY
-python3 bench.py --no-cpu-baseline --no-entropy > $OUT/c2.json 2>/dev/null
-python3 - <<PY
-import json
-d=json.load(open("$OUT/c2.json")); print("plain c2", round(d["value"]), round(d["ms_per_step"],3))
+for c in ("config2","config3","config5","config3_fp32kernels"):
+    d=json.load(open("$G/bench_%s.json"%c)); r=d["roofline"]
+    print(c, round(d["value"]), round(d["ms_per_step"],3), r["kernel"], round(r["avg_launch_ms"],4), round(r["frac"],4), d.get("cpu_baseline",{}).get("value"))
 PY
