@@ -147,6 +147,8 @@ def main():
                          "size of batch i enters the metric reduction of step i + depth")
     ap.add_argument("--coder-cus", type=int, default=0,
                     help="CUs reserved for the range coder's stream (0 = no CU masking)")
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="batches in flight: step i runs on stream i %% lanes (kernel tails of one batch overlap the next)")
     ap.add_argument("--no-entropy", action="store_true",
                     help="BASELINE config 2 (transforms + rate + metrics only).  The default is config 3: the "
                          "CDF tables and the range coder of the z,y strings also run on the GPU (second stream)")
@@ -223,9 +225,24 @@ def main():
 
     # warm-up; its last step runs with the kernel timer on so that the event pool (and the coder's)
     # exists before the clock starts
-    for i in range(args.warmup):
-        timer.enabled = i == args.warmup - 1
-        step()
+    # --lanes L: step i runs on stream i % L, so the tail of one batch's kernels (workgroups of a persistent kernel
+    # finish up to one tile apart) and its small layers overlap the next batch's; every lane is joined before the
+    # clock stops
+    lanes = None
+    if args.lanes > 1:
+        lanes = [torch.cuda.Stream() for _ in range(args.lanes)]
+        for ln in lanes:
+            ln.wait_stream(torch.cuda.current_stream())
+
+    def run_step(i):
+        if lanes is None:
+            return step()
+        with torch.cuda.stream(lanes[i % len(lanes)]):
+            return step()
+
+    for i in range(max(args.warmup, args.lanes if lanes else 0)):
+        timer.enabled = i == max(args.warmup, args.lanes if lanes else 0) - 1
+        run_step(i)
     timer.enabled = False
     per_step = timer.used + 1
     if not args.kernels:
@@ -245,9 +262,12 @@ def main():
     timer.enabled = True
     marks = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         marks.append(timer.mark())
-        step()
+        run_step(i)
+    if lanes is not None:
+        for ln in lanes:
+            torch.cuda.current_stream().wait_stream(ln)
     if coder is not None:
         last = coder.wait()                                      # strings of the final step
         extra = torch.zeros(4, dtype=torch.float64, device=dev)

@@ -46,14 +46,17 @@ class CompressionModel(nn.Module):
         self.max_nu = max_nu
         self.spatial_params = spatial_params
         self.N, self.M = N, M
-        self._fork = {}              # device index -> (side stream, fork event, join event)
+        self._fork = {}              # (device index, caller's stream) -> (side stream, fork event, join event)
 
-    def _hyper_fork(self, device):
-        f = self._fork.get(device.index)
+    def _hyper_fork(self, device, main):
+        # one side stream per stream the model is called on: two batches in flight on two streams must not share
+        # the fork / join events
+        key = (device.index, main.cuda_stream)
+        f = self._fork.get(key)
         if f is None:
             with torch.cuda.device(device):
                 f = (torch.cuda.Stream(priority=-1), torch.cuda.Event(), torch.cuda.Event())
-            self._fork[device.index] = f
+            self._fork[key] = f
         return f
 
     @staticmethod
@@ -102,7 +105,7 @@ class CompressionModel(nn.Module):
 
         if HYPER_STREAM:
             main = torch.cuda.current_stream(y.device)
-            side, forked, joined = self._hyper_fork(y.device)
+            side, forked, joined = self._hyper_fork(y.device, main)
             forked.record(main)
             with torch.cuda.stream(side):
                 side.wait_event(forked)
