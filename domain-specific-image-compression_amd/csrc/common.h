@@ -34,10 +34,15 @@ inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 #if defined(__HIPCC__)
 // GDN / IGDN of one value (layers.py:21-27): x / sqrt(beta + gamma x^2) or x * sqrt(...).
 // DSIC_EXACT_GDN=1 reproduces torch's op sequence with IEEE div/sqrt (~25 VALU ops per
-// element); the default uses v_rsq_f32 plus one Newton step (~9 ops, |rel. error| < 2^-22),
-// far below the fp32 summation-order noise of the convolution that feeds it.
+// element); the default uses v_rsq_f32 (1 ulp) and one multiply (~5 ops, |rel. error| < 2^-22, the class of
+// torch's own sqrt + divide roundings and far below the summation-order noise of the convolution that feeds it;
+// the 9 reference fixtures keep 0 latent flips on the fp32 kernels).  DSIC_GDN_NEWTON=1 adds a Newton step
+// on 1/sqrt(s) (measured: +1 % step time, no change in the fixtures' flips).
 #ifndef DSIC_EXACT_GDN
 #define DSIC_EXACT_GDN 0
+#endif
+#ifndef DSIC_GDN_NEWTON
+#define DSIC_GDN_NEWTON 0
 #endif
 __device__ __forceinline__ float gdn_apply(float v, float beta, float gamma, bool inverse) {
   const float s = __fadd_rn(beta, __fmul_rn(gamma, __fmul_rn(v, v)));
@@ -46,7 +51,9 @@ __device__ __forceinline__ float gdn_apply(float v, float beta, float gamma, boo
   return inverse ? __fmul_rn(v, d) : __fdiv_rn(v, d);
 #else
   float r = __builtin_amdgcn_rsqf(s);
+#if DSIC_GDN_NEWTON
   r = r * (1.5f - 0.5f * s * r * r);  // Newton step on 1/sqrt(s)
+#endif
   return inverse ? v * (s * r) : v * r;
 #endif
 }
@@ -62,9 +69,11 @@ __device__ __forceinline__ dsic_float2 gdn_pair(dsic_float2 v, dsic_float2 beta,
 #else
   const dsic_float2 s = __builtin_elementwise_fma(gamma, v * v, beta);
   dsic_float2 r = {__builtin_amdgcn_rsqf(s[0]), __builtin_amdgcn_rsqf(s[1])};
+#if DSIC_GDN_NEWTON
   const dsic_float2 h = (-0.5f * s) * r;
   const dsic_float2 c15 = {1.5f, 1.5f};
   r = r * __builtin_elementwise_fma(h, r, c15);  // Newton step on 1/sqrt(s)
+#endif
   return INV ? v * (s * r) : v * r;
 #endif
 }
