@@ -125,3 +125,21 @@ def test_sigma_z_is_deterministic_and_within_one_ulp_of_torch(L):
         diff += np.count_nonzero(got != want)
         n += ls.size
     assert diff <= 0.02 * n, (diff, n)
+
+
+def test_split_k_policy_depends_on_the_layer_geometry_only(L):
+    """dsic_wino_bf16_ksplit(H, W, Cin): layers with fewer than four 16x8-pixel tiles per image share a tile's
+    input channels between work items, in even runs of >= 4 sixteen-channel chunks.  There is no batch argument:
+    a patch's bits cannot depend on the batch it is in (tests/test_gpu_fullsize.py checks the invariance)."""
+    ks = L.dsic_wino_bf16_ksplit
+    assert ks(128, 128, 128) == 1 and ks(32, 32, 512) == 1          # many tiles per image
+    assert ks(16, 16, 512) == 2                                     # g_a.14 at 256x256: 2 tiles per image
+    assert ks(8, 8, 512) == 4 and ks(4, 4, 512) == 4                # h_a.4 / h_a.6: one (partial) tile
+    assert ks(16, 16, 128) == 2 and ks(16, 16, 192) == 2            # 8 / 12 chunks -> runs of 4 / 6
+    assert ks(8, 8, 128) == 2                                       # 8 chunks cannot make four runs of >= 4
+    assert ks(8, 8, 64) == 1 and ks(8, 8, 96) == 1                  # 4 / 6 chunks: no even split of >= 4
+    assert ks(0, 8, 128) == 1 and ks(8, 8, 100) == 1                # nonsense stays unsplit
+    for H, W, C in ((16, 16, 512), (8, 8, 512), (16, 16, 192), (24, 16, 256), (8, 40, 128)):
+        S = ks(H, W, C)
+        n = C // 16
+        assert S >= 1 and n % S == 0 and (S == 1 or ((n // S) >= 4 and (n // S) % 2 == 0))
