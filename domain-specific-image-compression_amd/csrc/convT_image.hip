@@ -92,28 +92,34 @@ __global__ __launch_bounds__(256, IMG_WGS) void convT_image_kernel(const ImgArgs
     goff[i] = g;
     loff[i] = lo;
   }
-  floatx4 stage[ISLOTS];
-  auto load_chunk = [&](int chunk) {
+  // Two chunks (32 channels = one 128-byte line per pixel) are loaded together and staged one after the other:
+  // loaded a chunk apart, the second 64-byte half of every line missed L2 again (2.5 MB of windows in flight per
+  // XCD pull 5 MB of lines through a 4 MB L2): 7.75 M 128-byte memory-side read requests per launch = 991 MB for
+  // a 537 MB input (TCC_EA0_RDREQ).
+  floatx4 stage[2][ISLOTS];
+  auto load_pair = [&](int chunk) {   // chunks `chunk` (even) and chunk + 1
 #pragma unroll
     for (int i = 0; i < ISLOTS; ++i) {
       const floatx4 z = {0.f, 0.f, 0.f, 0.f};
-      stage[i] = goff[i] >= 0 ? *(const floatx4*)(img + goff[i] + chunk * ICK) : z;
+      stage[0][i] = goff[i] >= 0 ? *(const floatx4*)(img + goff[i] + chunk * ICK) : z;
+      stage[1][i] = goff[i] >= 0 && chunk + 1 < C16 ? *(const floatx4*)(img + goff[i] + (chunk + 1) * ICK) : z;
     }
   };
-  auto store_chunk = [&]() {
+  auto store_chunk = [&](int half) {
 #pragma unroll
     for (int i = 0; i < ISLOTS; ++i)
       if (loff[i] >= 0) {
+        const floatx4 sv = half ? stage[1][i] : stage[0][i];
         if (BF16) {
           // pixel record: hi quads at +0..31, mid quads at +32..63 (bytes); loff = pix*IP + cq*4 floats
           uintx2 hi, mid;
-          img_split(stage[i], hi, mid);
+          img_split(sv, hi, mid);
           unsigned char* rec = (unsigned char*)lds + (size_t)(loff[i] / IP) * (IP * 4);
           const int cq = (loff[i] % IP) >> 2;
           *(uintx2*)(rec + cq * 8) = hi;
           *(uintx2*)(rec + 32 + cq * 8) = mid;
         } else {
-          *(floatx4*)(lds + loff[i]) = stage[i];
+          *(floatx4*)(lds + loff[i]) = sv;
         }
       }
   };
@@ -125,12 +131,12 @@ __global__ __launch_bounds__(256, IMG_WGS) void convT_image_kernel(const ImgArgs
   const int abase = ((wave * 4) * IW + r) * IP + 4 * q;
   const float* wl = a.w + r * 16 + 4 * q;  // + (tap*C16 + chunk)*256
 
-  load_chunk(0);
+  load_pair(0);
   for (int chunk = 0; chunk < C16; ++chunk) {
     __syncthreads();  // the previous chunk's window is no longer read
-    store_chunk();
+    store_chunk(chunk & 1);
     __syncthreads();
-    if (chunk + 1 < C16) load_chunk(chunk + 1);  // in flight during the MFMAs below
+    if ((chunk & 1) && chunk + 1 < C16) load_pair(chunk + 1);  // in flight during the MFMAs below
     floatx4 b = *(const floatx4*)(wl + (size_t)(0 * C16 + chunk) * 256);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
