@@ -26,6 +26,10 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
 FLAGS += os.environ.get("DSIC_EXTRA_FLAGS", "").split()   # e.g. -DWINO_RING=1 for A/B builds
+# per-file flags.  metrics.hip: the SLP vectorizer packs the 11-tap filter chains of ssim_level_kernel into
+# v_pk_fma_f32 with the weights duplicated into SGPR pairs - 200 spilled SGPRs (v_readlane in the loop) and a
+# v_mov per packed operand; plain v_fma_f32 chains are shorter and spill nothing.
+FILE_FLAGS = {"metrics.hip": ["-fno-slp-vectorize"]}
 
 
 def _sources():
@@ -38,7 +42,7 @@ def _deps_mtime():
 
 
 def _compile(src, obj):
-    cmd = [HIPCC, *FLAGS, "-c", src, "-o", obj]
+    cmd = [HIPCC, *FLAGS, *FILE_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -49,7 +53,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     # objects built with other flags (A/B and diagnostic builds set DSIC_EXTRA_FLAGS) are stale
     flag_file = os.path.join(OBJ, ".flags")
-    flag_str = " ".join(FLAGS)
+    flag_str = " ".join(FLAGS) + " | " + repr(sorted(FILE_FLAGS.items()))
     if not os.path.exists(flag_file) or open(flag_file).read() != flag_str:
         force = True
     hdr_m = _deps_mtime()

@@ -456,6 +456,13 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AQ(0), Bq[pi % RING][1], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AQ(1), Bq[pi % RING][0], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AQ(0), Bq[pi % RING][0], c, 0, 0, 0);
+          if (WB_ABL & 128) {   // ablation 128: a second M tile per U fragment (V re-read, 3 more MFMAs)
+#pragma unroll
+            for (int q = 0; q < P; ++q) Aq1[q] = *(const bf16x8*)(vb + pos_of(pi) * POSB + q * PLANEB + 8 * ROWB);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AQ(0), Bq[pi % RING][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AQ(1), Bq[pi % RING][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AQ(0), Bq[pi % RING][0], c, 0, 0, 0);
+          }
           acc[p0] = c;
         } else if (FIRST) {
 #pragma unroll
@@ -475,7 +482,7 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16_kernel(const Args a) {
           // a structurally zero position of THIS chunk is never multiplied: its fragments are not
           // fetched at all (the vector-memory path, 64 B/clk per CU, is what bounds this kernel).
           // Steps of the next chunk / tile (f >= 8) are fetched unconditionally.
-          if (!(ZSKIP && f < 8 && is_zero(f))) fetch(Bq[pi % RING], so);
+          if (!(ZSKIP && f < 8 && is_zero(f)) && !((WB_ABL & 64) && (pi & 1))) fetch(Bq[pi % RING], so);   // ablation 64: half of the U fetches
         }
       }
 #undef AQ

@@ -4,133 +4,269 @@
 // eval_selfcontained_entropy.py:154; third-party, not vendored in the
 // reference, so parity is pinned only by the repo's own oracle):
 // 11-tap Gaussian window (sigma 1.5), separable "valid" filtering of
-// X, Y, X*X, Y*Y, X*Y (rows first, then columns), C1=(0.01 L)^2, C2=(0.03 L)^2,
+// X, Y, X*X, Y*Y, X*Y (along H first, then along W), C1=(0.01 L)^2, C2=(0.03 L)^2,
 // cs = (2 s_xy + C2)/(s_x + s_y + C2), ssim = (2 m_x m_y + C1)/(m_x^2+m_y^2+C1)*cs,
 // spatial means per (image, channel), 2x2 average pooling (padding = size%2,
 // zeros counted) between levels, prod_l relu(v_l)^w_l, mean over channels.
-// One 32x16 output tile per workgroup, LDS-staged 42x26 halo tile, fixed-order fp64 partial
-// sums (deterministic).
+//
+// ssim_level_kernel streams: one WAVE owns a band of output rows of a 256-column strip (64 lanes x 4
+// adjacent columns, 16-byte global loads; planes of <= 128 / <= 64 columns share a wave two / four at a
+// time).  The filter along H runs out of an 11-row register ring (the loop is unrolled 11 times, so the
+// ring slots are compile-time registers), the filter along W through a wave-private LDS row (one
+// ds_write_b128 + four ds_read_b128 per map: 14 neighbours for 4 outputs) - no workgroup barrier
+// anywhere.  The 2x2 average pool that feeds the next level is produced by the wave that owns the rows
+// (even H, W % 4 == 0; other shapes use avgpool2_kernel).  Every output sums its 11 taps in ascending
+// order; fixed-order fp64 partial sums (deterministic run to run).
 #include "common.h"
 
 namespace dsic {
 
 #define WIN 11
-#define TSX 32                 // output tile: 32 x 16 per workgroup
-#define TSY 16
-#define TINX (TSX + WIN - 1)   // 42 x 26 input tile
-#define TINY (TSY + WIN - 1)
 
 struct GaussWin {
   float g[WIN];
 };
 
-// The scan is LDS-bound, not HBM-bound: every thread produces FOUR adjacent outputs along the
-// filter direction from 14 values held in registers (sliding window), 4x fewer LDS reads than one
-// output per thread.  Each output still sums its 11 taps in ascending order.
-__global__ __launch_bounds__(256) void ssim_level_kernel(const float* __restrict__ X,
-                                                         const float* __restrict__ Y,
-                                                         double* __restrict__ partial, int H, int W,
-                                                         int tiles_x, int tiles_y, float C1, float C2,
-                                                         int clamp_x, GaussWin gw) {
-  __shared__ float sx[TINY][TINX + 1], sy[TINY][TINX + 1];
-  __shared__ float tmp[5][TSY][TINX + 1];
-  __shared__ double red[2][4];
-  const int plane = blockIdx.z;
-  const int tx0 = blockIdx.x * TSX, ty0 = blockIdx.y * TSY;
+struct SsimGeom {
+  int segw, strips, rb, nbands, groups;
+};
+constexpr int SSIM_STRIP = 244;   // owned output columns per 256-column strip (256 - 10, rounded down to 4)
+
+static SsimGeom ssim_geom(int planes, int H, int W) {
+  SsimGeom g;
   const int Ho = H - (WIN - 1), Wo = W - (WIN - 1);
-  const float* xp = X + (size_t)plane * H * W;
-  const float* yp = Y + (size_t)plane * H * W;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < TINY * TINX; i += 256) {
-    const int r = i / TINX, c = i % TINX;
-    const int gy = ty0 + r, gx = tx0 + c;
-    float a = 0.f, b = 0.f;
-    if (gy < H && gx < W) {
-      a = xp[(size_t)gy * W + gx];
-      b = yp[(size_t)gy * W + gx];
-      if (clamp_x) a = fminf(fmaxf(a, 0.f), 1.f);
-    }
-    sx[r][c] = a;
-    sy[r][c] = b;
-  }
-  __syncthreads();
-  // pass 1: filter along H -> tmp[map][out_row][col]; thread = (column, group of 4 output rows)
-  if (tid < TINX * (TSY / 4)) {
-    const int c = tid % TINX, r0 = (tid / TINX) * 4;
-    float a[14], b[14], aa[14], bb[14], ab[14];
-#pragma unroll
-    for (int i = 0; i < 14; ++i) {
-      a[i] = sx[r0 + i][c];
-      b[i] = sy[r0 + i][c];
-      aa[i] = a[i] * a[i];
-      bb[i] = b[i] * b[i];
-      ab[i] = a[i] * b[i];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f;
-#pragma unroll
-      for (int k = 0; k < WIN; ++k) {
-        const float g = gw.g[k];
-        m0 += g * a[j + k];
-        m1 += g * b[j + k];
-        m2 += g * aa[j + k];
-        m3 += g * bb[j + k];
-        m4 += g * ab[j + k];
+  g.segw = W <= 64 ? 64 : W <= 128 ? 128 : 256;
+  g.strips = W <= 256 ? 1 : ceil_div(Wo, SSIM_STRIP);
+  g.groups = ceil_div(planes, 256 / g.segw);
+  // bands of output rows: about two waves per SIMD over the chip (2048 wave tasks), at least 16 rows each
+  // (every band re-reads 10 halo rows), an even count so that the 2x2 pooling pairs stay inside a band
+  // one round of waves: at most 2048 wave tasks (two per SIMD; more waves add nothing, the kernel is bound by vector
+  // instruction issue), at least 8 rows each (every band re-reads 10 halo rows)
+  const int maxb = 2048 / (g.groups * g.strips) > 0 ? 2048 / (g.groups * g.strips) : 1;
+  int rb = ceil_div(Ho, maxb);
+  if (rb < 8) rb = 8;
+  rb += rb & 1;
+  g.rb = rb;
+  g.nbands = ceil_div(Ho, rb);
+  return g;
+}
+
+template <int SEGW, bool VEC>
+__global__ __launch_bounds__(256, 2) void ssim_level_kernel(const float* __restrict__ X, const float* __restrict__ Y,
+                                                         double* __restrict__ partial, float* __restrict__ Xn,
+                                                         float* __restrict__ Yn, int planes, int H, int W, int rb,
+                                                         int nbands, int strips, float C1, float C2, int clamp_x,
+                                                         GaussWin gw) {
+  typedef float floatx4 __attribute__((ext_vector_type(4)));
+  typedef float floatx2 __attribute__((ext_vector_type(2)));
+  constexpr int LPS = SEGW / 4;        // lanes per plane segment
+  constexpr int NSEG = 64 / LPS;       // planes per wave
+  constexpr int ROWF = 256 + 16;       // floats per LDS map row: 256 columns + the 14-wide reads of the last lanes
+  __shared__ __attribute__((aligned(16))) float hbuf[4][5][ROWF];   // per wave: pair map (0,1) = rows 0-1, pair map (2,3) = rows 2-3, map 4 = row 4
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int groups = (planes + NSEG - 1) / NSEG;
+  const int task = blockIdx.x * 4 + wave;
+  if (task >= groups * strips * nbands) return;   // wave-uniform; the kernel has no barrier
+  const int band = task % nbands;
+  const int strip = (task / nbands) % strips;
+  const int group = task / (nbands * strips);
+  const int seg = lane / LPS, c4 = lane % LPS;
+  const int plane = group * NSEG + seg;
+  const bool pvalid = plane < planes;
+  const int col0 = strip * SSIM_STRIP + 4 * c4;
+  const int Ho = H - (WIN - 1), Wo = W - (WIN - 1);
+  const int orow0 = band * rb;
+  const int nout = min(rb, Ho - orow0);
+  const int own_end = band == nbands - 1 ? H : orow0 + rb;           // input rows this wave pools
+  const int col_end = strips == 1 ? Wo : min(Wo, (strip + 1) * SSIM_STRIP);   // output columns this wave owns
+  const bool pool = Xn != nullptr;
+  const int ocol_end = pvalid ? col_end : 0;   // no output column of an absent plane is counted
+  const float* xp = X + (size_t)(pvalid ? plane : 0) * H * W;
+  const float* yp = Y + (size_t)(pvalid ? plane : 0) * H * W;
+
+  auto load_row = [&](int r, floatx4& a, floatx4& b) {
+    a = floatx4{0.f, 0.f, 0.f, 0.f};
+    b = a;
+    if (VEC) {
+      if (pvalid && col0 < W) {
+        a = *(const floatx4*)(xp + (size_t)r * W + col0);
+        b = *(const floatx4*)(yp + (size_t)r * W + col0);
       }
-      tmp[0][r0 + j][c] = m0;
-      tmp[1][r0 + j][c] = m1;
-      tmp[2][r0 + j][c] = m2;
-      tmp[3][r0 + j][c] = m3;
-      tmp[4][r0 + j][c] = m4;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (pvalid && col0 + e < W) {
+          a[e] = xp[(size_t)r * W + col0 + e];
+          b[e] = yp[(size_t)r * W + col0 + e];
+        }
     }
+    if (clamp_x) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] = fminf(fmaxf(a[e], 0.f), 1.f);
+    }
+  };
+  // The five maps are filtered in packed pairs (v_pk_fma_f32: one instruction, two maps): (X, Y), (X*X, Y*Y), and
+  // X*Y alone.  Ring slot = one input row as four (x, y) pairs.
+  struct Row {
+    floatx2 p[4];
+  };
+  auto pack_row = [&](const floatx4& a, const floatx4& b) {
+    Row r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r.p[e] = floatx2{a[e], b[e]};
+    return r;
+  };
+  // 2x2 average of rows (r-1, r), r odd: same summation order as avgpool2_kernel
+  auto pool_rows = [&](int r, const Row& r0, const Row& r1) {
+    if (!(pool && (r & 1) && r < own_end && pvalid)) return;
+    if (col0 >= W || (strips > 1 && col0 >= (strip + 1) * SSIM_STRIP)) return;
+    const size_t o = ((size_t)plane * (H >> 1) + (r >> 1)) * (W >> 1) + (col0 >> 1);
+    // both planes at once: lane [0] = X, lane [1] = Y
+    const floatx2 q0 = (((r0.p[0] + r0.p[1]) + r1.p[0]) + r1.p[1]) * 0.25f;
+    const floatx2 q1 = (((r0.p[2] + r0.p[3]) + r1.p[2]) + r1.p[3]) * 0.25f;
+    *(floatx2*)(Xn + o) = floatx2{q0[0], q1[0]};
+    *(floatx2*)(Yn + o) = floatx2{q0[1], q1[1]};
+  };
+
+  Row ring[WIN];   // the 11 input rows under the current output row: slot k = tap k
+#pragma unroll
+  for (int i = 0; i < WIN - 1; ++i) {
+    floatx4 a, b;
+    load_row(orow0 + i, a, b);
+    ring[i] = pack_row(a, b);
+    if (i > 0) pool_rows(orow0 + i, ring[i - 1], ring[i]);
   }
-  __syncthreads();
-  // pass 2: filter along W; thread = (output row, group of 4 output columns)
+  floatx4 pfa, pfb;
+  load_row(orow0 + WIN - 1, pfa, pfb);
   double cs = 0.0, ss = 0.0;
-  if (tid < TSY * (TSX / 4)) {
-    const int r = tid / (TSX / 4), c0 = (tid % (TSX / 4)) * 4;
-    float m[5][4];
+  // LDS row of the wave: [pair map 0: 2 x ROWF][pair map 1: 2 x ROWF][map 4: ROWF]; a lane's four columns of a
+  // pair map are 32 contiguous bytes
+  float* const lds01 = &hbuf[wave][0][0] + 8 * lane;
+  float* const lds23 = &hbuf[wave][2][0] + 8 * lane;
+  float* const lds4 = &hbuf[wave][4][0] + 4 * lane;
+  // One output row per iteration; the ring is shifted by register moves (tap k = slot k).  (Unrolling 11 rows with
+  // rotating slot indices needs no moves but is > 100 KB of code: the instruction cache then bounds the kernel.)
+#pragma nounroll
+  for (int o = 0; o < nout; ++o) {
+    {
+      {
+        constexpr int u = 0;
+        const int r = orow0 + o + WIN - 1;
+        ring[WIN - 1] = pack_row(pfa, pfb);
+        if (o + 1 < nout) load_row(r + 1, pfa, pfb);
+        pool_rows(r, ring[WIN - 2], ring[WIN - 1]);
+        // filter along H, taps in ascending order, straight into the wave's LDS row
+        {
+          floatx2 m01[4], m23[4];
+          floatx4 m4;
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      float t[14];
+          for (int e = 0; e < 4; ++e) {
+            m01[e] = floatx2{0.f, 0.f};
+            m23[e] = floatx2{0.f, 0.f};
+            m4[e] = 0.f;
+          }
 #pragma unroll
-      for (int i = 0; i < 14; ++i) t[i] = tmp[q][r][c0 + i];
+          for (int k = 0; k < WIN; ++k) {
+            const floatx2 g2 = {gw.g[k], gw.g[k]};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float s = 0.f;
+            for (int e = 0; e < 4; ++e) {
+              const floatx2 v = ring[(u + k) % WIN].p[e];
+              m01[e] = __builtin_elementwise_fma(g2, v, m01[e]);
+              m23[e] = __builtin_elementwise_fma(g2, v * v, m23[e]);
+              m4[e] = __builtin_fmaf(gw.g[k], v[0] * v[1], m4[e]);
+            }
+          }
+          *(floatx4*)(lds01) = floatx4{m01[0][0], m01[0][1], m01[1][0], m01[1][1]};
+          *(floatx4*)(lds01 + 4) = floatx4{m01[2][0], m01[2][1], m01[3][0], m01[3][1]};
+          *(floatx4*)(lds23) = floatx4{m23[0][0], m23[0][1], m23[1][0], m23[1][1]};
+          *(floatx4*)(lds23 + 4) = floatx4{m23[2][0], m23[2][1], m23[3][0], m23[3][1]};
+          *(floatx4*)(lds4) = m4;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // filter along W through the wave's LDS row (in-order per wave: no barrier, only the data wait)
+        floatx2 h01[4], h23[4];
+        float h4[4];
+        {
+          floatx2 t[14];
 #pragma unroll
-        for (int k = 0; k < WIN; ++k) s += gw.g[k] * t[j + k];
-        m[q][j] = s;
+          for (int v = 0; v < 7; ++v) {
+            const floatx4 x = *(const floatx4*)(lds01 + 4 * v);
+            t[2 * v] = floatx2{x[0], x[1]};
+            t[2 * v + 1] = floatx2{x[2], x[3]};
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) h01[j] = floatx2{0.f, 0.f};
+#pragma unroll
+          for (int k = 0; k < WIN; ++k)   // the four outputs' chains side by side (a dependent v_pk_fma_f32 needs a wait state)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h01[j] = __builtin_elementwise_fma(floatx2{gw.g[k], gw.g[k]}, t[j + k], h01[j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          floatx2 t[14];
+#pragma unroll
+          for (int v = 0; v < 7; ++v) {
+            const floatx4 x = *(const floatx4*)(lds23 + 4 * v);
+            t[2 * v] = floatx2{x[0], x[1]};
+            t[2 * v + 1] = floatx2{x[2], x[3]};
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) h23[j] = floatx2{0.f, 0.f};
+#pragma unroll
+          for (int k = 0; k < WIN; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h23[j] = __builtin_elementwise_fma(floatx2{gw.g[k], gw.g[k]}, t[j + k], h23[j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          float t[16];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const floatx4 x = *(const floatx4*)(lds4 + 4 * v);
+            t[4 * v] = x[0]; t[4 * v + 1] = x[1]; t[4 * v + 2] = x[2]; t[4 * v + 3] = x[3];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) h4[j] = 0.f;
+#pragma unroll
+          for (int k = 0; k < WIN; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h4[j] = __builtin_fmaf(gw.g[k], t[j + k], h4[j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float rcs[4], rss[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          // computed by every lane (no branch), counted by the lanes that own the output
+          const floatx2 musq = h01[j] * h01[j];            // (mu1^2, mu2^2)
+          const float mu12 = h01[j][0] * h01[j][1];
+          const floatx2 sg = h23[j] - musq;                // (sigma1^2, sigma2^2)
+          const float s12 = h4[j] - mu12;
+          // a * rcp(b) (v_rcp_f32, 1 ulp) instead of the IEEE division sequence (11 instructions each, 8 per row):
+          // 1e-7 relative per pixel against a 1e-4 bar on the mean
+          const float csv = (2.f * s12 + C2) * __builtin_amdgcn_rcpf(sg[0] + sg[1] + C2);
+          const float sv = ((2.f * mu12 + C1) * __builtin_amdgcn_rcpf(musq[0] + musq[1] + C1)) * csv;
+          const bool ok = col0 + j < ocol_end;
+          rcs[j] = ok ? csv : 0.f;
+          rss[j] = ok ? sv : 0.f;
+        }
+        // the row's four values in fp32 (fixed order), the running sums in fp64
+        cs += (double)(((rcs[0] + rcs[1]) + rcs[2]) + rcs[3]);
+        ss += (double)(((rss[0] + rss[1]) + rss[2]) + rss[3]);
+#pragma unroll
+        for (int i = 0; i < WIN - 1; ++i) ring[i] = ring[i + 1];
       }
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (ty0 + r < Ho && tx0 + c0 + j < Wo) {
-        const float m0 = m[0][j], m1 = m[1][j];
-        const float mu1_sq = m0 * m0, mu2_sq = m1 * m1, mu12 = m0 * m1;
-        const float s1 = m[2][j] - mu1_sq, s2 = m[3][j] - mu2_sq, s12 = m[4][j] - mu12;
-        const float csv = (2.f * s12 + C2) / (s1 + s2 + C2);
-        const float sv = ((2.f * mu12 + C1) / (mu1_sq + mu2_sq + C1)) * csv;
-        cs += (double)csv;
-        ss += (double)sv;
-      }
-    }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    cs += __shfl_down(cs, o, 64);
-    ss += __shfl_down(ss, o, 64);
+  for (int o = LPS / 2; o > 0; o >>= 1) {
+    cs += __shfl_down(cs, o, LPS);
+    ss += __shfl_down(ss, o, LPS);
   }
-  if ((tid & 63) == 0) {
-    red[0][tid >> 6] = cs;
-    red[1][tid >> 6] = ss;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    const size_t o = ((size_t)plane * tiles_y * tiles_x + (size_t)blockIdx.y * tiles_x + blockIdx.x) * 2;
-    partial[o] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-    partial[o + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  if (c4 == 0 && pvalid) {
+    const size_t o = (((size_t)plane * strips + strip) * nbands + band) * 2;
+    partial[o] = cs;
+    partial[o + 1] = ss;
   }
 }
 
@@ -218,14 +354,10 @@ __global__ __launch_bounds__(256) void sqerr_kernel(const float* __restrict__ a,
 
 using namespace dsic;
 
-extern "C" int dsic_ssim_level(const float* X, const float* Y, double* partial, double* means,
-                               int planes, int H, int W, float C1, float C2, int clamp_x,
-                               void* stream) {
-  DSIC_REQUIRE(X && Y && partial && means, "ssim_level: null pointer");
-  DSIC_REQUIRE(planes > 0 && H >= WIN && W >= WIN, "ssim_level: plane %dx%d smaller than the 11x11 window", H, W);
+static int ssim_level_launch(const float* X, const float* Y, double* partial, double* means, float* Xn, float* Yn,
+                             int planes, int H, int W, float C1, float C2, int clamp_x, hipStream_t st) {
   const int Ho = H - (WIN - 1), Wo = W - (WIN - 1);
-  const int tx = ceil_div(Wo, TSX), ty = ceil_div(Ho, TSY);
-  DSIC_REQUIRE(planes <= 65535, "ssim_level: too many planes (%d)", planes);
+  const SsimGeom g = ssim_geom(planes, H, W);
   GaussWin gw;
   {
     // pytorch-msssim _fspecial_gauss_1d: exp(-(i-5)^2/(2*1.5^2)) normalised, in fp32
@@ -237,18 +369,53 @@ extern "C" int dsic_ssim_level(const float* X, const float* Y, double* partial, 
     }
     for (int i = 0; i < WIN; ++i) gw.g[i] /= s;
   }
-  hipLaunchKernelGGL(ssim_level_kernel, dim3(tx, ty, planes), dim3(256), 0, (hipStream_t)stream, X, Y,
-                     partial, H, W, tx, ty, C1, C2, clamp_x, gw);
+  const int ntasks = g.groups * g.strips * g.nbands;
+  const dim3 grid((unsigned)ceil_div(ntasks, 4)), block(256);
+  const bool vec = W % 4 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 16) == 0;
+#define SSIM_LAUNCH(S, V)                                                                                           \
+  hipLaunchKernelGGL((ssim_level_kernel<S, V>), grid, block, 0, st, X, Y, partial, Xn, Yn, planes, H, W, g.rb, g.nbands, \
+                     g.strips, C1, C2, clamp_x, gw)
+  if (g.segw == 64) { if (vec) SSIM_LAUNCH(64, true); else SSIM_LAUNCH(64, false); }
+  else if (g.segw == 128) { if (vec) SSIM_LAUNCH(128, true); else SSIM_LAUNCH(128, false); }
+  else { if (vec) SSIM_LAUNCH(256, true); else SSIM_LAUNCH(256, false); }
+#undef SSIM_LAUNCH
   int rc = check_launch("ssim_level");
   if (rc) return rc;
-  hipLaunchKernelGGL(ssim_reduce_kernel, dim3(ceil_div(planes, 64)), dim3(64), 0, (hipStream_t)stream,
-                     partial, means, tx * ty, 1.0 / ((double)Ho * Wo), planes);
+  hipLaunchKernelGGL(ssim_reduce_kernel, dim3(ceil_div(planes, 64)), dim3(64), 0, st, partial, means,
+                     g.strips * g.nbands, 1.0 / ((double)Ho * Wo), planes);
   return check_launch("ssim_reduce");
 }
 
+extern "C" int dsic_ssim_level(const float* X, const float* Y, double* partial, double* means,
+                               int planes, int H, int W, float C1, float C2, int clamp_x,
+                               void* stream) {
+  DSIC_REQUIRE(X && Y && partial && means, "ssim_level: null pointer");
+  DSIC_REQUIRE(planes > 0 && H >= WIN && W >= WIN, "ssim_level: plane %dx%d smaller than the 11x11 window", H, W);
+  return ssim_level_launch(X, Y, partial, means, nullptr, nullptr, planes, H, W, C1, C2, clamp_x, (hipStream_t)stream);
+}
+
+extern "C" int dsic_ssim_level_pool_fused(int H, int W) { return H % 2 == 0 && W % 4 == 0; }
+
+extern "C" int dsic_ssim_level_pool(const float* X, const float* Y, double* partial, double* means, float* Xn,
+                                    float* Yn, int planes, int H, int W, float C1, float C2, int clamp_x,
+                                    void* stream) {
+  DSIC_REQUIRE(X && Y && partial && means && Xn && Yn, "ssim_level_pool: null pointer");
+  DSIC_REQUIRE(planes > 0 && H >= WIN && W >= WIN, "ssim_level_pool: plane %dx%d smaller than the 11x11 window", H, W);
+  if (dsic_ssim_level_pool_fused(H, W) && (uintptr_t)X % 16 == 0 && (uintptr_t)Y % 16 == 0 && (uintptr_t)Xn % 8 == 0 &&
+      (uintptr_t)Yn % 8 == 0)
+    return ssim_level_launch(X, Y, partial, means, Xn, Yn, planes, H, W, C1, C2, clamp_x, (hipStream_t)stream);
+  // odd sizes (padded pooling): the level and the two pools as separate passes
+  int rc = ssim_level_launch(X, Y, partial, means, nullptr, nullptr, planes, H, W, C1, C2, clamp_x, (hipStream_t)stream);
+  if (rc) return rc;
+  rc = dsic_avgpool2(X, Xn, planes, H, W, clamp_x, stream);
+  if (rc) return rc;
+  return dsic_avgpool2(Y, Yn, planes, H, W, 0, stream);
+}
+
 extern "C" int64_t dsic_ssim_partial_doubles(int planes, int H, int W) {
-  if (H < WIN || W < WIN) return 0;
-  return (int64_t)planes * ceil_div(H - WIN + 1, TSY) * ceil_div(W - WIN + 1, TSX) * 2;
+  if (H < WIN || W < WIN || planes <= 0) return 0;
+  const SsimGeom g = ssim_geom(planes, H, W);
+  return (int64_t)planes * g.strips * g.nbands * 2;
 }
 
 extern "C" int dsic_avgpool2(const float* src, float* dst, int planes, int H, int W, int clamp,

@@ -72,6 +72,9 @@ SIGNATURES = {
     "dsic_ssim_partial_doubles": (c_int64, [c_int, c_int, c_int]),
     "dsic_ssim_level": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, ctypes.c_float, ctypes.c_float,
                                 c_int, _P]),
+    "dsic_ssim_level_pool_fused": (c_int, [c_int, c_int]),
+    "dsic_ssim_level_pool": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, ctypes.c_float, ctypes.c_float,
+                                     c_int, _P]),
     "dsic_avgpool2": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "dsic_msssim_finalize": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "dsic_sqerr_per_image": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P]),

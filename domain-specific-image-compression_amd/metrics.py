@@ -48,15 +48,17 @@ def _levels(X, Y, n_levels, data_range, clamp_x):
     for lvl in range(n_levels):
         h, w = x.shape[-2], x.shape[-1]
         partial = torch.empty(L.dsic_ssim_partial_doubles(planes, h, w), dtype=torch.float64, device=X.device)
-        _lib.check(L.dsic_ssim_level(_p(x), _p(y), _p(partial), _p(means[lvl]), planes, h, w, C1, C2, clamp,
-                                     _stream()), "ssim_level")
         if lvl < n_levels - 1:
+            # the level and the 2x2 average pool that feeds the next one, in one pass over x and y
             ho, wo = (h + 2 * (h % 2) - 2) // 2 + 1, (w + 2 * (w % 2) - 2) // 2 + 1
             nx = torch.empty((B, C, ho, wo), dtype=torch.float32, device=X.device)
             ny = torch.empty_like(nx)
-            _lib.check(L.dsic_avgpool2(_p(x), _p(nx), planes, h, w, clamp, _stream()), "avgpool2")
-            _lib.check(L.dsic_avgpool2(_p(y), _p(ny), planes, h, w, 0, _stream()), "avgpool2")
+            _lib.check(L.dsic_ssim_level_pool(_p(x), _p(y), _p(partial), _p(means[lvl]), _p(nx), _p(ny), planes, h, w,
+                                              C1, C2, clamp, _stream()), "ssim_level_pool")
             x, y, clamp = nx, ny, 0
+        else:
+            _lib.check(L.dsic_ssim_level(_p(x), _p(y), _p(partial), _p(means[lvl]), planes, h, w, C1, C2, clamp,
+                                         _stream()), "ssim_level")
     return means
 
 

@@ -294,6 +294,16 @@ int64_t dsic_ssim_partial_doubles(int planes, int H, int W);
 int dsic_ssim_level(const float* X, const float* Y, double* partial,
                     double* means, int planes, int H, int W, float C1, float C2,
                     int clamp_x, void* stream);
+/* The same level plus the inputs of the next one: Xn, Yn [planes,Hn,Wn] =
+ * F.avg_pool2d(kernel=2, padding=size%2) of (clamped) X and of Y
+ * (pytorch-msssim's downsampling between levels, modelseval.py:80-85), Hn =
+ * (H + 2*(H%2) - 2)/2 + 1.  For even H and W % 4 == 0
+ * (dsic_ssim_level_pool_fused) the pool comes out of the pass that reads the
+ * level; other shapes run dsic_ssim_level + 2 x dsic_avgpool2. */
+int dsic_ssim_level_pool_fused(int H, int W);
+int dsic_ssim_level_pool(const float* X, const float* Y, double* partial,
+                         double* means, float* Xn, float* Yn, int planes, int H,
+                         int W, float C1, float C2, int clamp_x, void* stream);
 /* F.avg_pool2d(kernel=2, padding=size%2) between MS-SSIM levels. */
 int dsic_avgpool2(const float* src, float* dst, int planes, int H, int W,
                   int clamp, void* stream);
