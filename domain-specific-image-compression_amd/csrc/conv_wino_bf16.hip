@@ -649,6 +649,8 @@ extern "C" int dsic_split_wino_weight_bf16(const float* u_f32, void* dst, int Co
   return check_launch("split_wino_weight_bf16");
 }
 
+int dsic_wbm_launch(wb::Args& a, hipStream_t st);   // conv_wino_bf16m.hip
+
 static int wb_launch(wb::Args& a, hipStream_t st) {
   const int B = a.B, H = a.H, W = a.W;
   a.tiles_x = ceil_div(W, 16);
@@ -668,6 +670,7 @@ static int wb_launch(wb::Args& a, hipStream_t st) {
                    (int64_t)H * W * a.ostride * 4 * (a.nphase == 4 ? 4 : 1) < ((int64_t)1 << 31),
                "conv_wino_bf16: one image must stay below 2 GiB (32-bit offsets inside an image)");
   DSIC_REQUIRE(a.u_phase_bytes * a.nphase < ((int64_t)1 << 31), "conv_wino_bf16: transformed weights must stay below 2 GiB");
+  if (a.ksplit == 1 && dsic_wino_bf16_m64(H, W, a.Cin, a.nphase)) return dsic_wbm_launch(a, st);   // large layers: conv_wino_bf16m.hip
   a.ntiles = (int)nt;
   a.nt_out = a.ksplit == 1 && (int64_t)B * H * W * a.Cout * 4 * (a.nphase == 4 ? 4 : 1) > (300ll << 20);
   int dev = 0;

@@ -47,6 +47,7 @@ SIGNATURES = {
     "dsic_conv3x3_wino_bf16_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                             c_int, c_int, c_int, _P, _P]),
     "dsic_wino_bf16_ksplit": (c_int, [c_int, c_int, c_int]),
+    "dsic_wino_bf16_m64": (c_int, [c_int, c_int, c_int, c_int]),
     "dsic_conv3x3_wino_bf16_splitk_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
                                                    c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "dsic_conv_transpose2d_wino_bf16_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -163,6 +163,10 @@ int dsic_conv3x3_wino_bf16_nhwc(const float* in, const void* u_planes,
  * shared by S work items, whose partial sums (partials: S buffers of the size of `out`, caller-owned) are
  * added in fixed order, biased and activated by a second launch. */
 int dsic_wino_bf16_ksplit(int H, int W, int Cin);
+/* 1 when dsic_conv3x3_wino_bf16_nhwc / dsic_conv_transpose2d_wino_bf16_nhwc run the layer with the 64-tile,
+ * two-pass kernel (csrc/conv_wino_bf16m.hip: H and W multiples of 16, at least 16 work items per image; nphase = 4
+ * for ConvTranspose2d, 1 otherwise) - a function of the layer geometry only, like the split-K rule. */
+int dsic_wino_bf16_m64(int H, int W, int Cin, int nphase);
 int dsic_conv3x3_wino_bf16_splitk_nhwc(const float* in, const void* u_planes,
                                        const float* bias, const float* beta,
                                        const float* gamma, float* out, int B, int H, int W,

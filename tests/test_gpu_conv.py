@@ -209,6 +209,12 @@ WINO_CASES = [
     (70, 32, 128, 8, 16, "none"),     # one tile per workgroup, single chunk
     (300, 32, 64, 8, 16, "relu"),     # single-chunk layer, more tiles than workgroups (ticket loop)
     (4, 128, 128, 96, 160, "gdn"),    # 480 tiles: every workgroup takes several through the ticket
+    # H, W multiples of 16 and >= 16 work items per image: the 64-tile two-pass kernel (conv_wino_bf16m.hip)
+    (2, 128, 128, 64, 64, "gdn"),     # g_a.8 / g_s.6
+    (1, 128, 64, 64, 96, "igdn"),     # half of the channel groups idle, H != W
+    (2, 192, 128, 64, 64, "relu"),    # 12 chunks per pass
+    (3, 64, 128, 64, 80, "none"),     # 4 chunks per pass: the shortest pipeline
+    (5, 128, 128, 128, 128, "gdn"),   # g_a.4 / g_s.10: 320 work items, every workgroup takes a second one
 ]
 
 
@@ -259,7 +265,10 @@ def test_winograd_conv_vs_oracle(ops, B, Cin, Cout, H, W, act, variant):
 
 @pytest.mark.parametrize("B,Cs,Cout,H,W,act", [(1, 128, 128, 32, 64, "gdn"), (2, 128, 128, 20, 36, "none"),
                                                (1, 64, 64, 16, 16, "relu"), (3, 128, 128, 6, 10, "gdn"),
-                                               (2, 128, 128, 192, 224, "gdn")])
+                                               (2, 128, 128, 192, 224, "gdn"),
+                                               # outputs of 64x64 / 64x80 / 128x128: the 64-tile two-pass kernel
+                                               (2, 128, 128, 128, 128, "gdn"), (1, 64, 64, 128, 160, "none"),
+                                               (3, 128, 128, 256, 256, "relu")])
 @pytest.mark.parametrize("variant", ["fp32", "bf16"])
 def test_conv5x5_stride2_as_winograd_over_space_to_depth(ops, B, Cs, Cout, H, W, act, variant):
     """conv(C,C,5,2) == 3x3 Winograd over the space-to-depth input with 4*C channels."""
@@ -298,9 +307,35 @@ def test_space_to_depth_epilogues(ops):
     assert torch.equal(ops.conv3x3_wino_nhwc(a, w2, b, 128, s2d_out=True), ops.space_to_depth(y))
 
 
+def test_two_pass_kernel_stores(ops):
+    """The 64-tile two-pass kernel stores straight from the accumulators: the space-to-depth order and a
+    channel slice of a wider tensor equal the plain output; a second launch gives the same bits."""
+    from dsic_amd import lib
+    L = lib.load()
+    assert L.dsic_wino_bf16_m64(64, 96, 128, 1) == 1 and L.dsic_wino_bf16_m64(64, 90, 128, 1) == 0
+    assert L.dsic_wino_bf16_m64(32, 32, 128, 4) == 1 and L.dsic_wino_bf16_m64(32, 32, 128, 1) == 0
+    x = _rand((2, 64, 96, 128), 65, 1.0).cuda()
+    b = _rand((128,), 66, 0.5).cuda()
+    beta = (0.5 + torch.rand(128, generator=torch.Generator().manual_seed(4))).cuda()
+    gamma = (0.02 + 0.28 * torch.rand(128, generator=torch.Generator().manual_seed(5))).cuda()
+    u = ops.split_wino_weight_bf16(ops.pack_wino_weight(_rand((128, 128, 3, 3), 67, 0.05).cuda()), 128, 128)
+    y = ops.conv3x3_wino_nhwc(x, u, b, 128, ops.ACT_GDN, beta, gamma)
+    assert torch.equal(ops.conv3x3_wino_nhwc(x, u, b, 128, ops.ACT_GDN, beta, gamma), y)
+    assert torch.equal(ops.conv3x3_wino_nhwc(x, u, b, 128, ops.ACT_GDN, beta, gamma, s2d_out=True), ops.space_to_depth(y))
+    u64 = ops.split_wino_weight_bf16(ops.pack_wino_weight(_rand((64, 128, 3, 3), 68, 0.05).cuda()), 64, 128)
+    y64 = ops.conv3x3_wino_nhwc(x, u64, b[:64].contiguous(), 64, ops.ACT_RELU)
+    wide = torch.full((2, 64, 96, 192), -7.0, device="cuda")
+    ops.conv3x3_wino_nhwc(x, u64, b[:64].contiguous(), 64, ops.ACT_RELU, out=wide, out_coff=64)
+    assert torch.equal(wide[..., 64:128], y64)
+    assert float(wide[..., :64].max()) == -7.0 and float(wide[..., 128:].max()) == -7.0
+
+
 @pytest.mark.parametrize("B,Cin,Cout,H,W,act", [(2, 192, 128, 5, 7, "igdn"), (1, 128, 128, 16, 24, "igdn"),
                                                 (1, 128, 128, 9, 17, "relu"), (9, 128, 128, 2, 3, "none"),
-                                                (2, 128, 64, 32, 16, "none"), (3, 128, 128, 40, 72, "igdn")])
+                                                (2, 128, 64, 32, 16, "none"), (3, 128, 128, 40, 72, "igdn"),
+                                                # 16 and more (tile, phase) items per image: the 64-tile two-pass kernel
+                                                (2, 128, 128, 32, 32, "igdn"), (1, 128, 64, 32, 48, "none"),
+                                                (1, 192, 128, 32, 32, "relu"), (3, 128, 128, 64, 64, "igdn")])
 @pytest.mark.parametrize("variant", ["fp32", "bf16"])
 def test_conv_transpose_winograd_vs_oracle(ops, B, Cin, Cout, H, W, act, variant):
     x = _rand((B, Cin, H, W), 71, 2.0)
