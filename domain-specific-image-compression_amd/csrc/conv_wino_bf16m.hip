@@ -66,8 +66,9 @@ constexpr int WINITEMS = WINW * WINH * 4;       // float4 items of one chunk: 12
 constexpr int WINB = WINITEMS * 16;             // 20736 bytes
 constexpr int NLOAD = (WINITEMS + 255) / 256;   // 6 window loads per helper thread
 constexpr int STAGEOFF = SLOTOFF + 64;
-constexpr int STAMPOFF = STAGEOFF + 2 * WINB;
-constexpr int PARAMOFF = STAMPOFF + (WBM_STAMP ? 2048 : 0);   // bias, beta, gamma: [3][128] floats
+constexpr int NWIN = 3;                          // window buffers: one being transformed, two in flight (LDS-DMA)
+constexpr int STAMPOFF = STAGEOFF + NWIN * WINB;
+constexpr int PARAMOFF = STAMPOFF + (WBM_STAMP ? 1024 : 0);   // bias, beta, gamma: [3][128] floats
 constexpr int LDS_TOTAL = PARAMOFF + 3 * 128 * 4;
 constexpr int THREADS = 768;
 constexpr int RING = 2;
@@ -75,12 +76,12 @@ constexpr int RING = 2;
 static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
 
 #if WBM_STAMP
-static __device__ long long wbm_stamps[256 * 256];
+static __device__ long long wbm_stamps[256 * 256];   // low 32 bits of s_memtime (the LDS copy is 4 bytes per stamp)
 #define MSTAMP(w, i)                                                                                   \
   do {                                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
     if (lane == 0 && wave == (w) && tile_count == 3 && (i) >= 0 && (i) < 128)                          \
-      ((long long*)(lds_raw + STAMPOFF))[((w) == 0 ? 0 : 128) + (i)] = __builtin_amdgcn_s_memtime();   \
+      ((unsigned*)(lds_raw + STAMPOFF))[((w) == 0 ? 0 : 128) + (i)] = (unsigned)__builtin_amdgcn_s_memtime();   \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
   } while (0)
 #else
@@ -169,22 +170,27 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16m_kernel(const Args a) 
       const intx4 v = {item, tile - row * a.tiles_x, row % a.tiles_y, row / a.tiles_y};
       *(intx4*)(slots + 4 * s) = v;
     };
+    // Input side.  The 18x18-pixel window of the tile (halo 1; 16 channels of the chunk, fp32) goes from global
+    // memory straight into one of three LDS window buffers (buffer_load_dwordx4 ... lds: no registers, no staging
+    // stores): item i = (pixel i >> 2, channel quad i & 3) lies at byte 16 i of the buffer, i.e. the 64 lanes of a
+    // wave-instruction fill 1 KB at M0 + 16 lane.  Helper wave hw issues the items hw*64 + 256 j + lane (j < 6; the
+    // last, partial piece belongs to the lanes 0..15 of wave 0).  The loads are inline asm: the compiler does not see
+    // them (it would drain an LDS-DMA in front of every barrier), so the waits are counted here:
+    //   phase sg: issue the window of chunk-pass sg + 3; transform sg + 1; wait for the window of sg + 2 (all but
+    //             this wave's newest NDMA loads); barrier.
+    // A window has two phases to arrive; an out-of-image pixel is an out-of-range offset (the DMA writes zeros).
     struct WinAim {
       unsigned off[NLOAD];
-      __amdgpu_buffer_rsrc_t rsrc;
+      uintx4 rsrc;
     };
     WinAim am;
-    unsigned stage_off[NLOAD];
-#pragma unroll
-    for (int j = 0; j < NLOAD; ++j) {
-      const int i = ht + 256 * j;
-      stage_off[j] = (unsigned)((i >> 2) * (CK * 4) + (i & 3) * 16);
-    }
+    const int hw = wave - 8;
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)lds_raw;
     auto aim = [&](WinAim& m, const Tile& t0) {
       Tile t = t0;
       if (WBM_ABL & 1) { t.n = 0; t.tx = 0; t.ty = 0; }
-      m.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)t.n * a.H * a.W * Cin), 0,
-                                                 a.H * a.W * Cin * 4, 0x00020000);
+      const unsigned long long base = (unsigned long long)(a.in + (size_t)t.n * a.H * a.W * Cin);
+      m.rsrc = uintx4{(unsigned)base, (unsigned)(base >> 32) & 0xFFFFu, (unsigned)(a.H * a.W * Cin * 4), 0x00020000u};
 #pragma unroll
       for (int j = 0; j < NLOAD; ++j) {
         const int i = ht + 256 * j;
@@ -199,17 +205,26 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16m_kernel(const Args a) 
 #pragma unroll
       for (int j = 0; j < NLOAD; ++j) m.off[j] = 0x80000000u;
     };
-    auto issue = [&](floatx4 (&r)[NLOAD], int chunk) {
+    auto dma = [&](int wbuf, int chunk) {
+      const uintx4 rs = {(unsigned)__builtin_amdgcn_readfirstlane((int)am.rsrc[0]), (unsigned)__builtin_amdgcn_readfirstlane((int)am.rsrc[1]),
+                         (unsigned)__builtin_amdgcn_readfirstlane((int)am.rsrc[2]), (unsigned)__builtin_amdgcn_readfirstlane((int)am.rsrc[3])};
+      const unsigned soff = (unsigned)(chunk * (CK * 4));
 #pragma unroll
-      for (int j = 0; j < NLOAD; ++j)
-        r[j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(am.rsrc, am.off[j], chunk * (CK * 4), 0));
+      for (int j = 0; j < NLOAD; ++j) {
+        const unsigned m0v = lds_base + (unsigned)(STAGEOFF + wbuf * WINB + 16 * (hw * 64 + 256 * j));
+        if (j < NLOAD - 1 || ht < WINITEMS - 256 * (NLOAD - 1))   // the last piece: lanes 0..15 of helper wave 0
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                       :: "s"(m0v), "v"(am.off[j]), "s"(rs), "s"(soff) : "memory");
+      }
     };
-    auto stage = [&](const floatx4 (&r)[NLOAD], int wbuf) {
-      unsigned char* wbp = lds_raw + STAGEOFF + wbuf * WINB;
-#pragma unroll
-      for (int j = 0; j < NLOAD; ++j)
-        if (j < NLOAD - 1 || ht < WINITEMS - 256 * (NLOAD - 1)) *(floatx4*)(wbp + stage_off[j]) = r[j];
+    // number of loads one dma() adds to this wave's vector-memory counter
+    const bool last_piece = hw == 0;   // wave-uniform
+    auto wait_all_but_newest = [&](int groups) {   // groups = 0, 1 or 2 windows may stay in flight
+      if (groups == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (groups == 1) { if (last_piece) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
+      else { if (last_piece) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
     };
+    static_assert(NLOAD == 6, "the vmcnt immediates above count 6 (5) loads per window");
     // this thread's 4x4 patch inside a staged window: rows 2*pty .. +3, columns 2*ptx .. +3, quad pq
     const int patch0 = ((2 * pty) * WINW + 2 * ptx) * (CK * 4) + pq * 16;
     auto split_store = [&](floatx4 v, unsigned char* dst) {
@@ -282,23 +297,22 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16m_kernel(const Args a) 
     }
     __syncthreads();  // P0
     Tile cur = read_slot(0);
-    floatx4 R0[NLOAD], R1[NLOAD];
     int ticket_pre = a.ntiles;
     aim(am, cur);
-    issue(R0, 0);
-    issue(R1, 1);
-    stage(R0, 0);
-    stage(R1, 1);
-    issue(R0, 2);
-    issue(R1, 3);
+    dma(0, 0);
+    dma(1, 1);
+    dma(2, 2);
     if (ht == 0 && read_slot(1).item < a.ntiles) ticket_pre = next_ticket();
-    __syncthreads();  // P1: windows of chunks 0 and 1 are staged
+    wait_all_but_newest(2);
+    __syncthreads();  // P1: the window of chunk 0 has landed (every helper wave has waited for its pieces)
     {
       unsigned zxi, znu;
       zero_of(cur, 0, zxi, znu);
       commit(0, 0, false, zxi, znu);    // V[0] = (cur, pass A, chunk 0)
     }
+    wait_all_but_newest(1);             // window of chunk 1
     __syncthreads();  // P
+    int wq = 1;                         // window buffer of the chunk-pass transformed in the coming phase
     int s_nxt = 1, s_wr = 2;
     while (cur.item < a.ntiles) {
       const Tile nxt = read_slot(s_nxt);
@@ -306,31 +320,34 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16m_kernel(const Args a) 
       tile_count++;
       // One phase (chunk-pass sg of this tile; targets past the last one belong to the next tile).  Every phase
       // issues the same memory operations whatever the tile: with no next tile the aim points nowhere.
-      auto phase = [&](floatx4 (&R)[NLOAD], int sg) {
+      auto phase = [&](int sg) {
         MSTAMP(8, 4 * sg);
-        stage(R, sg & 1);                                                // window of chunk-pass sg + 2
+        {
+          const int k3 = sg + 3;                                         // window of chunk-pass sg + 3
+          if (k3 == L) {   // from here on every load is for the next tile
+            if (more) aim(am, nxt); else aim_nowhere(am);
+          }
+          const int k3w = k3 < L ? k3 : k3 - L;
+          dma(wq >= 1 ? wq - 1 : 2, k3w < nchunks ? k3w : k3w - nchunks);   // buffer (wq + 2) % 3
+        }
         MSTAMP(8, 4 * sg + 1);
         {
           unsigned zxi, znu;                                             // target sg + 1
           const int tg = sg + 1;
           const bool passB = tg >= nchunks && tg < L;
           if (tg < L) zero_of(cur, passB ? tg - nchunks : tg, zxi, znu); else zero_of(nxt, 0, zxi, znu);
-          commit(tg & 1, tg & 1, passB, zxi, znu);
+          commit(wq, tg & 1, passB, zxi, znu);
         }
+        wq = wq == 2 ? 0 : wq + 1;
+        wait_all_but_newest(1);                                          // window of chunk-pass sg + 2
         MSTAMP(8, 4 * sg + 2);
         __syncthreads();  // B_sg
         MSTAMP(8, 4 * sg + 3);
-        const int k4 = sg + 4;
-        if (k4 == L) {   // from here on every load is for the next tile
-          if (more) aim(am, nxt); else aim_nowhere(am);
-        }
-        const int k4w = k4 < L ? k4 : k4 - L;
-        issue(R, k4w < nchunks ? k4w : k4w - nchunks);
       };
       if (ht == 0 && more) post(s_wr, ticket_pre);
       for (int sg = 0; sg < L; sg += 2) {
-        phase(R0, sg);
-        phase(R1, sg + 1);
+        phase(sg);
+        phase(sg + 1);
         if (sg + 2 == nchunks) {   // the MFMA waves fold pass A into pass B's accumulators (exchange through LDS,
           // region B = V buffer 1: not to be written before M4)
           __syncthreads();  // M1
@@ -347,8 +364,8 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16m_kernel(const Args a) 
     }
 #if WBM_STAMP
     if (wave == 8) {
-      wbm_stamps[blockIdx.x * 256 + 128 + lane] = ((long long*)(lds_raw + STAMPOFF))[128 + lane];
-      wbm_stamps[blockIdx.x * 256 + 192 + lane] = ((long long*)(lds_raw + STAMPOFF))[192 + lane];
+      wbm_stamps[blockIdx.x * 256 + 128 + lane] = (long long)((unsigned*)(lds_raw + STAMPOFF))[128 + lane];
+      wbm_stamps[blockIdx.x * 256 + 192 + lane] = (long long)((unsigned*)(lds_raw + STAMPOFF))[192 + lane];
     }
 #endif
     if (ht == 0) {
@@ -639,8 +656,8 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16m_kernel(const Args a) 
   }
 #if WBM_STAMP
   if (wave == 0) {
-    wbm_stamps[blockIdx.x * 256 + lane] = ((long long*)(lds_raw + STAMPOFF))[lane];
-    wbm_stamps[blockIdx.x * 256 + 64 + lane] = ((long long*)(lds_raw + STAMPOFF))[64 + lane];
+    wbm_stamps[blockIdx.x * 256 + lane] = (long long)((unsigned*)(lds_raw + STAMPOFF))[lane];
+    wbm_stamps[blockIdx.x * 256 + 64 + lane] = (long long)((unsigned*)(lds_raw + STAMPOFF))[64 + lane];
   }
 #endif
   };
