@@ -57,6 +57,11 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if not os.path.exists(flag_file) or open(flag_file).read() != flag_str:
         force = True
     hdr_m = _deps_mtime()
+    # objects whose source has left the tree are removed, never linked
+    live = {os.path.basename(src) + ".o" for src in _sources()}
+    for o in glob.glob(os.path.join(OBJ, "*.o")):
+        if os.path.basename(o) not in live:
+            os.remove(o)
     jobs, objs = [], []
     for src in _sources():
         obj = os.path.join(OBJ, os.path.basename(src) + ".o")

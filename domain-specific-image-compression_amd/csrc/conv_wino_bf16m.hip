@@ -679,7 +679,7 @@ using namespace dsic;
 
 // Which layers take this kernel: a function of the layer geometry only (never of the batch size: a patch's bits
 // must not depend on the batch it is in).  H and W multiples of 16 (no ragged tiles: the stores are unmasked) and
-// at least 16 work items per image.
+// at least 4 work items per image (32x32 outputs; ConvTranspose2d: 16x16 inputs).
 extern "C" int dsic_wino_bf16_m64(int H, int W, int Cin, int nphase) {
   static int mode = -1;   // DSIC_WINO_M64=0: never (A/B runs)
   if (mode < 0) {
@@ -688,7 +688,7 @@ extern "C" int dsic_wino_bf16_m64(int H, int W, int Cin, int nphase) {
   }
   if (!mode) return 0;
   if (H <= 0 || W <= 0 || H % 16 || W % 16 || Cin < 64 || Cin % 32) return 0;
-  const int min_items = mode > 1 ? mode : 16;
+  const int min_items = mode > 1 ? mode : 4;
   return (H / 16) * (W / 16) * nphase >= min_items;
 }
 

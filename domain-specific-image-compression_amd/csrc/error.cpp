@@ -15,4 +15,4 @@ void set_error(const char* fmt, ...) {
 }  // namespace dsic
 
 extern "C" const char* dsic_last_error(void) { return dsic::g_err; }
-extern "C" int dsic_abi_version(void) { return 2; }
+extern "C" int dsic_abi_version(void) { return 3; }

@@ -244,6 +244,20 @@ def _tight_lmax(meta, minimum=32):
     return max(minimum, (L + 7) // 8 * 8)
 
 
+TABLE_FLOW_VERSION = 2     # 1: float64 tables (round 1); 2: float32 CPU-torch operation order
+
+
+def numerics_tag() -> int:
+    """What a decoder must share with the encoder to rebuild the same coder tables: the table flow, and the
+    arithmetic of the kernels that recompute sigma / nu from the decoded z (h_s: code/modelv2/
+    eval_selfcontained_entropy.py:100-106).  bits 0-7 table flow version, bit 8 split-bf16 Winograd kernels
+    (DSIC_WINO_BF16), bit 9 Winograd at all (DSIC_WINOGRAD), bits 16-31 the library's ABI version.  A stream carries
+    the tag of its encoder; custom_decompress refuses a stream whose tag is not its own."""
+    from . import layers as _layers
+    return (TABLE_FLOW_VERSION | (int(bool(_layers.WINO_BF16)) << 8) | (int(bool(_layers.USE_WINOGRAD)) << 9)
+            | ((int(_lib.load().dsic_abi_version()) & 0xFFFF) << 16))
+
+
 @torch.no_grad()
 def custom_compress(model, x, tail=10, Lmax=DEFAULT_LMAX):
     """eval_selfcontained_entropy.py:26-74.  Returns the reference's dict:
@@ -277,6 +291,7 @@ def custom_compress(model, x, tail=10, Lmax=DEFAULT_LMAX):
         "shape_y": c["shape_y"], "shape_z": c["shape_z"],
         "min_y": [int(m[0]) for m in meta], "max_y": [int(m[0] + m[1] - 1) for m in meta],
         "min_z": [int(m[2]) for m in meta], "max_z": [int(m[2] + m[3] - 1) for m in meta],
+        "numerics": numerics_tag(),        # beyond the reference's keys (:68-74): see numerics_tag()
     }
 
 
@@ -293,6 +308,11 @@ def _upload_strings(strings, which, dev):
 def custom_decompress(model, compressed, Lmax=None):
     """eval_selfcontained_entropy.py:76-123: decode z, re-run h_s, decode y, run g_s, clamp."""
     dev = next(model.parameters()).device
+    tag = compressed.get("numerics")
+    if tag is not None and int(tag) != numerics_tag():
+        raise EntropyError(f"custom_decompress: the stream was written with numerics tag {int(tag):#x}, this decoder "
+                           f"is {numerics_tag():#x} (table flow / kernel arithmetic differ: the coder tables would "
+                           "not match and the latents would decode to garbage)")
     strings = compressed["strings"]
     B = len(strings)
     _, M, Hy, Wy = compressed["shape_y"]
@@ -338,17 +358,19 @@ def real_bpp(compressed, H, W):
 
 # ---- container: the reference keeps the compressed patch batch as an in-memory dict (:68-74);
 # this is that dict as one byte string, so the strings can leave the process ------------------
-_MAGIC = b"DSIC1\x00"
+_MAGIC = b"DSIC2\x00"      # DSIC1: rounds 1-2, no numerics tag (float64 / float32 tables both wrote it: not decodable
+_MAGIC_V1 = b"DSIC1\x00"   # safely any more, refused)
 
 
 def pack_container(compressed) -> bytes:
     """dict of custom_compress -> bytes.  Layout (little endian):
-    magic(6) | B,My,Hy,Wy,Nz,Hz,Wz (7 x uint32) | per image: min_y,max_y,min_z,max_z (4 x int32),
-    len_z,len_y (2 x uint32) | per image: z bytes, y bytes."""
+    magic(6) | numerics tag (uint32, numerics_tag()) | B,My,Hy,Wy,Nz,Hz,Wz (7 x uint32) | per image:
+    min_y,max_y,min_z,max_z (4 x int32), len_z,len_y (2 x uint32) | per image: z bytes, y bytes."""
     import struct
     B, My, Hy, Wy = compressed["shape_y"]
     _, Nz, Hz, Wz = compressed["shape_z"]
-    head = [_MAGIC, struct.pack("<7I", B, My, Hy, Wy, Nz, Hz, Wz)]
+    tag = int(compressed.get("numerics", numerics_tag()))
+    head = [_MAGIC, struct.pack("<I", tag), struct.pack("<7I", B, My, Hy, Wy, Nz, Hz, Wz)]
     body = []
     for b in range(B):
         zs, ys = compressed["strings"][b]
@@ -361,10 +383,14 @@ def pack_container(compressed) -> bytes:
 def unpack_container(blob: bytes):
     """Inverse of pack_container."""
     import struct
+    if blob[:6] == _MAGIC_V1:
+        raise ValueError("DSIC1 container: written before the numerics tag existed (its coder tables may be the float64 "
+                         "ones of round 1); re-encode")
     if blob[:6] != _MAGIC:
         raise ValueError("not a DSIC container")
-    B, My, Hy, Wy, Nz, Hz, Wz = struct.unpack_from("<7I", blob, 6)
-    off = 6 + 28
+    (tag,) = struct.unpack_from("<I", blob, 6)
+    B, My, Hy, Wy, Nz, Hz, Wz = struct.unpack_from("<7I", blob, 10)
+    off = 10 + 28
     meta = [struct.unpack_from("<4i2I", blob, off + 24 * b) for b in range(B)]
     off += 24 * B
     strings = []
@@ -378,4 +404,4 @@ def unpack_container(blob: bytes):
         raise ValueError("truncated or oversized DSIC container")
     return {"strings": strings, "shape_y": [B, My, Hy, Wy], "shape_z": [B, Nz, Hz, Wz],
             "min_y": [m[0] for m in meta], "max_y": [m[1] for m in meta],
-            "min_z": [m[2] for m in meta], "max_z": [m[3] for m in meta]}
+            "min_z": [m[2] for m in meta], "max_z": [m[3] for m in meta], "numerics": tag}

@@ -23,13 +23,6 @@ USE_WINOGRAD = os.environ.get("DSIC_WINOGRAD", "1") != "0"
 # Winograd position GEMMs on the bf16 MFMA path with operands split into bf16 planes (fp32-class
 # results, csrc/conv_wino_bf16.hip); DSIC_WINO_BF16=0 selects the fp32-input MFMA kernel.
 WINO_BF16 = os.environ.get("DSIC_WINO_BF16", "1") != "0"
-# DSIC_DIRECT_5S2=1: 5x5 stride-2 layers with at least DSIC_DIRECT_5S2_MIN_TILES 16x8-pixel output tiles run as a
-# direct split-bf16 implicit GEMM (csrc/conv5s2_bf16.hip) instead of Winograd over space-to-depth.  Off by
-# default: measured 3.16 ms against 3.08 ms per step for g_a.2/6/10 (it executes 2x the MFMA work at 0.43 of the
-# bf16 peak; the chip clocks lower under that load), and a size-dependent kernel choice would make a patch's
-# latents depend on the batch it is in.
-DIRECT_5S2 = os.environ.get("DSIC_DIRECT_5S2", "0") == "1"
-DIRECT_5S2_MIN_TILES = int(os.environ.get("DSIC_DIRECT_5S2_MIN_TILES", "0"))
 
 
 class _GammaConv(nn.Module):
@@ -126,7 +119,9 @@ class Conv2d(_ConvBase):
     def use_winograd_s2(self):
         """5x5 stride-2 layers run as a 3x3 Winograd conv over the space-to-depth input (4*Cin
         channels) when the producing layer can write that layout."""
-        if not (USE_WINOGRAD and self.kernel_size == 5 and self.stride == 2 and self.in_channels % 8 == 0
+        # both Winograd kernels need 4*Cin as a multiple of 128 over the space-to-depth input (Cin % 32 == 0); other
+        # widths (cfg.MODEL.N is configurable in the reference's train.py) take the direct implicit GEMM
+        if not (USE_WINOGRAD and self.kernel_size == 5 and self.stride == 2 and self.in_channels % 32 == 0
                 and self.out_channels % 4 == 0 and self.out_channels >= 64):
             return False
         # wider outputs (g_a.14: 128 -> 192, layers.py:72) run as channel slices of <= 128 into one tensor;
@@ -177,14 +172,6 @@ class Conv2d(_ConvBase):
                                       out_coff=lo, split_k=self.split_k,
                                       algo_flops=2.0 * B * H2 * W2 * (hi - lo) * self.in_channels * 25)
             return out
-        if (x_is_s2d and DIRECT_5S2 and WINO_BF16 and not s2d_out and self.kernel_size == 5 and self.in_channels >= 64
-                and self.in_channels % 16 == 0 and self.out_channels <= 128 and act in (ops.ACT_NONE, ops.ACT_GDN, ops.ACT_RELU)
-                and x.shape[0] * (-(-x.shape[1] // 8)) * (-(-x.shape[2] // 16)) >= DIRECT_5S2_MIN_TILES):
-            # large 5x5/s2 layers: direct split-bf16 implicit GEMM (half the weight stream of the Winograd form)
-            key = self._key()
-            if getattr(self, "_w5", None) is None or self._w5_key != key:
-                self._w5, self._w5_key = ops.pack_conv5s2_bf16_weight(self.weight), key
-            return ops.conv5s2_bf16_nhwc(x, self._w5, self.bias, self.out_channels, act, beta, gamma)
         if x_is_s2d:
             B, H2, W2, _ = x.shape
             return ops.conv3x3_wino_nhwc(x, self.packed_wino(), self.bias, self.out_channels, act, beta, gamma,

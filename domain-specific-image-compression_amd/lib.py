@@ -52,9 +52,6 @@ SIGNATURES = {
                                                    c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "dsic_conv_transpose2d_wino_bf16_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
                                                      _P, _P]),
-    "dsic_conv5s2_bf16_weight_bytes": (c_int64, [c_int, c_int]),
-    "dsic_pack_conv5s2_bf16_weight": (c_int, [_P, _P, c_int, c_int, _P]),
-    "dsic_conv5s2_bf16_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "dsic_conv_first_nchw": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "dsic_conv_first_u8hwc": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "dsic_image_u8hwc_to_f32nchw": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -229,7 +229,9 @@ def conv_transpose2d_wino_nhwc(x, u_packed4, bias, Cout, act=ACT_NONE, beta=None
     wino_tiles = 4 * B * (-(-H // 8)) * (-(-W // 16)) * 32
     if u_packed4.dtype == torch.uint8:
         nprod = 3 if wino_bf16_planes() == 2 else 6
-        _timed("conv_wino_bf16_kernel<2>", 2.0 * B * H * W * Cout * Cin * 25,
+        # large layers run on the 64-tile two-pass kernel (conv_wino_bf16m.hip): the symbol the profiler will show
+        m64 = bool(L.dsic_wino_bf16_m64(H, W, Cin, 4))
+        _timed("conv_wino_bf16m_kernel<2>" if m64 else "conv_wino_bf16_kernel<2>", 2.0 * B * H * W * Cout * Cin * 25,
                lambda: _lib.check(L.dsic_conv_transpose2d_wino_bf16_nhwc(_p(x), _p(u_packed4), _p(bias), _p(beta),
                                                                          _p(gamma), _p(out), B, H, W, Cin, Cout, act,
                                                                          _p(_ticket(x.device)), _stream()),
@@ -283,7 +285,8 @@ def conv3x3_wino_nhwc(x, u_packed, bias, Cout, act=ACT_NONE, beta=None, gamma=No
                        ksplit, _p(partials), _p(_ticket(x.device)), _stream()), "conv3x3_wino_bf16_splitk_nhwc"),
                    exec_flops=2.0 * nprod * wino_tiles * (12.25 if s2d_in else 16) * Cin * round_up(Cout, 32))
             return out
-        _timed("conv_wino_bf16_kernel<1>" if s2d_in else "conv_wino_bf16_kernel<0>",
+        m64 = "m" if L.dsic_wino_bf16_m64(H, W, Cin, 1) else ""   # 64-tile two-pass kernel (conv_wino_bf16m.hip)
+        _timed(f"conv_wino_bf16{m64}_kernel<1>" if s2d_in else f"conv_wino_bf16{m64}_kernel<0>",
                algo_flops if algo_flops is not None else 2.0 * B * H * W * Cout * Cin * 9,
                lambda: _lib.check(L.dsic_conv3x3_wino_bf16_nhwc(_p(x), _p(u_packed), _p(bias), _p(beta), _p(gamma),
                                                                 _p(out), B, H, W, Cin, Cout, act, int(bool(s2d_out)),
@@ -311,35 +314,6 @@ def to_tensor_u8(x_u8_nhwc: torch.Tensor) -> torch.Tensor:
     B, H, W, C = x.shape
     out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
     _lib.check(_lib.load().dsic_image_u8hwc_to_f32nchw(_p(x), _p(out), B, C, H, W, _stream()), "to_tensor_u8")
-    return out
-
-
-def pack_conv5s2_bf16_weight(w: torch.Tensor) -> torch.Tensor:
-    """nn.Conv2d(Cs, Cout, 5, stride 2) weight [Cout,Cs,5,5] -> bf16 planes of the direct split-bf16 kernel."""
-    w = _f32c(w, "pack_conv5s2_bf16_weight")
-    Cout, Cs, k, k2 = w.shape
-    if k != 5 or k2 != 5:
-        raise ValueError("pack_conv5s2_bf16_weight: kernel must be 5x5")
-    L = _lib.load()
-    dst = torch.empty(L.dsic_conv5s2_bf16_weight_bytes(Cout, Cs), dtype=torch.uint8, device=w.device)
-    _lib.check(L.dsic_pack_conv5s2_bf16_weight(_p(w), _p(dst), Cout, Cs, _stream()), "pack_conv5s2_bf16_weight")
-    return dst
-
-
-def conv5s2_bf16_nhwc(x_s2d, w_planes, bias, Cout, act=ACT_NONE, beta=None, gamma=None):
-    """conv(Cs,Cout,5,2) + fused activation, direct split-bf16 implicit GEMM over the space-to-depth image
-    x_s2d [B,H,W,4*Cs] -> [B,H,W,Cout]."""
-    x = _f32c(x_s2d, "conv5s2_bf16_nhwc")
-    B, H, W, C4 = x.shape
-    Cs = C4 // 4
-    out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
-    L = _lib.load()
-    tiles = B * (-(-H // 8)) * (-(-W // 16))
-    _timed("conv5s2_bf16_kernel", 2.0 * B * H * W * Cout * Cs * 25,
-           lambda: _lib.check(L.dsic_conv5s2_bf16_nhwc(_p(x), _p(w_planes), _p(bias), _p(beta), _p(gamma), _p(out), B, H, W,
-                                                       Cs, Cout, act, _p(_ticket(x.device)), _stream()),
-                              "conv5s2_bf16_nhwc"),
-           exec_flops=2.0 * 3 * tiles * 128 * 25 * Cs * round_up(Cout, 32))
     return out
 
 

@@ -164,7 +164,7 @@ int dsic_conv3x3_wino_bf16_nhwc(const float* in, const void* u_planes,
  * added in fixed order, biased and activated by a second launch. */
 int dsic_wino_bf16_ksplit(int H, int W, int Cin);
 /* 1 when dsic_conv3x3_wino_bf16_nhwc / dsic_conv_transpose2d_wino_bf16_nhwc run the layer with the 64-tile,
- * two-pass kernel (csrc/conv_wino_bf16m.hip: H and W multiples of 16, at least 16 work items per image; nphase = 4
+ * two-pass kernel (csrc/conv_wino_bf16m.hip: H and W multiples of 16, at least 4 work items per image; nphase = 4
  * for ConvTranspose2d, 1 otherwise) - a function of the layer geometry only, like the split-K rule. */
 int dsic_wino_bf16_m64(int H, int W, int Cin, int nphase);
 int dsic_conv3x3_wino_bf16_splitk_nhwc(const float* in, const void* u_planes,
@@ -178,19 +178,6 @@ int dsic_conv_transpose2d_wino_bf16_nhwc(const float* in, const void* u_planes4,
                                          const float* gamma, float* out, int B,
                                          int H, int W, int Cin, int Cout, int act,
                                          void* ticket, void* stream);
-
-/* conv(Cs, Cout, 5, stride 2) + bias + GDN/ReLU (code/modelv2/layers.py:54,60,65) as a direct implicit
- * GEMM on split-bf16 MFMAs over the space-to-depth image [B][H][W][4*Cs] (H, W = output size) that the
- * producing layer writes (csrc/conv5s2_bf16.hip): 25 live (tap, channel block) pairs, half the weight
- * bytes of the Winograd form.  Cs a multiple of 16, >= 64; Cout <= 128.  Weights from the reference's
- * [Cout][Cs][5][5] tensor by dsic_pack_conv5s2_bf16_weight (dsic_conv5s2_bf16_weight_bytes bytes). */
-int64_t dsic_conv5s2_bf16_weight_bytes(int Cout, int Cs);
-int dsic_pack_conv5s2_bf16_weight(const float* w_oihw5, void* dst, int Cout, int Cs,
-                                  void* stream);
-int dsic_conv5s2_bf16_nhwc(const float* in_s2d, const void* w_planes, const float* bias,
-                           const float* beta, const float* gamma, float* out, int B,
-                           int H, int W, int Cs, int Cout, int act, void* ticket,
-                           void* stream);
 
 /* First analysis layer conv(Cimg,Cout,3,1) + optional GDN/ReLU (layers.py:51)
  * read straight from the NCHW image [B,Cimg,H,W] (Cimg 3 or 4) with K = 9*Cimg;

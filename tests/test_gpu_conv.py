@@ -313,7 +313,7 @@ def test_two_pass_kernel_stores(ops):
     from dsic_amd import lib
     L = lib.load()
     assert L.dsic_wino_bf16_m64(64, 96, 128, 1) == 1 and L.dsic_wino_bf16_m64(64, 90, 128, 1) == 0
-    assert L.dsic_wino_bf16_m64(32, 32, 128, 4) == 1 and L.dsic_wino_bf16_m64(32, 32, 128, 1) == 0
+    assert L.dsic_wino_bf16_m64(16, 16, 128, 4) == 1 and L.dsic_wino_bf16_m64(16, 16, 128, 1) == 0 and L.dsic_wino_bf16_m64(32, 32, 128, 1) == 1
     x = _rand((2, 64, 96, 128), 65, 1.0).cuda()
     b = _rand((128,), 66, 0.5).cuda()
     beta = (0.5 + torch.rand(128, generator=torch.Generator().manual_seed(4))).cuda()
@@ -382,37 +382,6 @@ def test_conv5x5_stride2_192_channels_as_two_winograd_slices(ops, B, H, W):
     assert got.shape == ref.shape
     err = float((got - ref).abs().max())
     assert err <= _tol(ref, 128 * 25) * 6 * _BF16_TOL["bf16"], (err, float(ref.abs().max()))
-
-
-@pytest.mark.parametrize("B,Cs,Cout,H,W,act", [(1, 128, 128, 32, 64, "gdn"), (2, 128, 128, 20, 36, "none"),
-                                               (1, 64, 64, 16, 16, "relu"), (3, 128, 128, 6, 10, "gdn"),
-                                               (2, 128, 128, 192, 224, "gdn"), (40, 128, 64, 16, 32, "none")])
-def test_conv5x5_stride2_direct_split_bf16(ops, B, Cs, Cout, H, W, act):
-    """conv(C,C,5,2) as the direct split-bf16 implicit GEMM over the space-to-depth input
-    (csrc/conv5s2_bf16.hip; layers.py:54,60,65 at the sizes where it replaces the Winograd form)."""
-    x = _rand((B, Cs, H, W), 91, 2.0)
-    w = _rand((Cout, Cs, 5, 5), 92, (Cs * 25) ** -0.5 * 2)
-    b = _rand((Cout,), 93, 0.5)
-    beta_p = torch.sqrt(0.5 + torch.rand(Cout, generator=torch.Generator().manual_seed(4)) + 2 ** -18)
-    gam_p = torch.sqrt(0.02 + 0.28 * torch.rand(Cout, generator=torch.Generator().manual_seed(5)) + 2 ** -18)
-    ref = O._conv({"p.weight": w, "p.bias": b}, "p", x, 2)
-    code = {"none": ops.ACT_NONE, "gdn": ops.ACT_GDN, "relu": ops.ACT_RELU}[act]
-    if act == "gdn":
-        ref = O.gdn(ref, beta_p, gam_p.view(-1, 1, 1, 1), False)
-    elif act == "relu":
-        ref = torch.relu(ref)
-    xs = ops.space_to_depth(_nhwc(x).cuda())
-    y = ops.conv5s2_bf16_nhwc(xs, ops.pack_conv5s2_bf16_weight(w.cuda()), b.cuda(), Cout, code,
-                              (beta_p ** 2 - 2 ** -18).cuda(), (gam_p ** 2 - 2 ** -18).cuda())
-    got = ops.nhwc_to_nchw(y).cpu()
-    assert got.shape == ref.shape
-    err = float((got - ref).abs().max())
-    print(f"[direct bf16] err/|ref|max = {err / float(ref.abs().max()):.2e}")
-    assert err <= _tol(ref, Cs * 25) * 6 * _BF16_TOL["bf16"], (err, float(ref.abs().max()))
-    # twice in a row: the ticket re-arms itself, results are deterministic
-    y2 = ops.conv5s2_bf16_nhwc(xs, ops.pack_conv5s2_bf16_weight(w.cuda()), b.cuda(), Cout, code,
-                               (beta_p ** 2 - 2 ** -18).cuda(), (gam_p ** 2 - 2 ** -18).cuda())
-    assert torch.equal(y, y2)
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W,act,s2d_in,s2d_out", [

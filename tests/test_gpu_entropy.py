@@ -160,12 +160,25 @@ def test_container_round_trip(model):
     blob = entropy.pack_container(c)
     back = entropy.unpack_container(blob)
     assert back == c
-    assert len(blob) == 6 + 28 + 24 * 2 + sum(len(s) for e in c["strings"] for s in e)
+    assert len(blob) == 6 + 4 + 28 + 24 * 2 + sum(len(s) for e in c["strings"] for s in e)
     assert torch.equal(entropy.custom_decompress(model, back), model(x, "round")["x_hat"].clamp(0, 1))
     with pytest.raises(ValueError):
         entropy.unpack_container(blob[:-1])
     with pytest.raises(ValueError):
         entropy.unpack_container(b"nope" + blob)
+    # the header carries the encoder's numerics tag (table flow, kernel arithmetic of h_s, ABI version): a stream
+    # written by another variant - e.g. DSIC_WINO_BF16=0, whose sigma / nu differ in the last bits - is refused
+    # instead of decoding to garbage latents, and so is a container of the rounds before the tag existed
+    assert c["numerics"] == entropy.numerics_tag() and (c["numerics"] & 0xFF) == entropy.TABLE_FLOW_VERSION
+    other = dict(back, numerics=back["numerics"] ^ (1 << 8))
+    with pytest.raises(entropy.EntropyError):
+        entropy.custom_decompress(model, other)
+    with pytest.raises(entropy.EntropyError):
+        entropy.custom_decompress(model, entropy.unpack_container(entropy.pack_container(other)))
+    with pytest.raises(ValueError):
+        entropy.unpack_container(b"DSIC1\x00" + blob[10:])
+    legacy = {k: v for k, v in c.items() if k != "numerics"}     # the reference's own dict (no tag): accepted
+    assert torch.equal(entropy.custom_decompress(model, legacy), model(x, "round")["x_hat"].clamp(0, 1))
 
 
 @pytest.mark.parametrize("spread", [4, 40, 120])
