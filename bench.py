@@ -141,7 +141,19 @@ def main():
     ap.add_argument("--channels", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernels", action="store_true", help="also print the per-kernel event timings to stderr")
-    ap.add_argument("--streams-per-wg", type=int, default=4, help="range-coder waves per workgroup (1..16)")
+    ap.add_argument("--streams-per-wg", type=int, default=1,
+                    help="range-coder waves per workgroup (1..16; 1: a wave has its CU's scalar unit to itself, "
+                         "4.4 instead of 5.1 ms per batch and a 1 %% faster step than 4)")
+    ap.add_argument("--decode", action="store_true",
+                    help="also time entropy.custom_decompress of the same batch (eval_selfcontained_entropy.py:76-123): "
+                         "adds a `decoder` object")
+    ap.add_argument("--e2e", action="store_true",
+                    help="also time the step from pinned-host uint8 [B,H,W,C] images to strings + lengths in pinned host "
+                         "memory (modelseval.py:164, eval_selfcontained_entropy.py:68-74): adds an `e2e` object; `value` "
+                         "stays the HBM-resident figure")
+    ap.add_argument("--spatial-params", action="store_true",
+                    help="the spatial_params=True branch (layers.py:127-129,143-145, model.py:49-51): per-element sigma / nu "
+                         "heads, one coder table row per latent element")
     ap.add_argument("--coder-depth", type=int, default=2,
                     help="batches whose strings may be in the coder at once (side streams, round-robin); the coded "
                          "size of batch i enters the metric reduction of step i + depth")
@@ -171,8 +183,11 @@ def main():
     from dsic_amd.model import CompressionModel
 
     B, H, W, C = args.batch, args.size, args.size, args.channels
-    sd = S.make_state_dict(seed=S.WEIGHT_SEED, in_ch=C)
-    model = CompressionModel(N=128, M=192, spatial_params=False, min_nu=2, max_nu=100.0, in_ch=C)
+    if args.lanes > 1 and not args.no_entropy and args.coder_depth % args.lanes:
+        raise SystemExit("--lanes must divide --coder-depth (the lanes share the coder's side streams and buffers)")
+    spatial = bool(args.spatial_params)
+    sd = S.make_state_dict(seed=S.WEIGHT_SEED, in_ch=C, spatial_params=spatial)
+    model = CompressionModel(N=128, M=192, spatial_params=spatial, min_nu=2, max_nu=100.0, in_ch=C)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     model = model.to(dev).eval()
     # this rank's slice of the global batch, resident in HBM before timing
@@ -282,6 +297,77 @@ def main():
     tot = totals.cpu().numpy()
     n_img = tot[2]
     value = args.steps * B * world / elapsed
+    if coder is not None:
+        err = int(coder.last["err"].item())
+        if err:
+            raise SystemExit(f"range coder reported error flags {err:#x} (support wider than Lmax?): mean_bpp_coded would be wrong")
+
+    decoder_stats = e2e_stats = None
+    if args.decode and rank == 0:
+        # Decode side: the strings of one batch as Python bytes (the reference's dict) -> upload, z tables,
+        # range decode z, h_s, y tables, range decode y, g_s, clamp.  Wall time per call, host work included.
+        comp = entropy.custom_compress(model, x)
+        ref_hat = model(x, quant_mode="round")["x_hat"].clamp(0, 1)
+        x_dec = entropy.custom_decompress(model, comp)
+        exact = bool(torch.equal(x_dec, ref_hat))
+        torch.cuda.synchronize()
+        reps = max(3, min(args.steps, 10))
+        td = time.perf_counter()
+        for _ in range(reps):
+            entropy.custom_decompress(model, comp)
+        torch.cuda.synchronize()
+        dms = (time.perf_counter() - td) / reps * 1e3
+        n_sym = B * (model.M * (H // 16) * (W // 16) + model.N * (H // 64) * (W // 64))
+        decoder_stats = {
+            "ms_per_batch": dms, "images_per_s": B / dms * 1e3, "symbols_per_s": n_sym / dms * 1e3,
+            "string_bytes_per_batch": sum(len(t) for e in comp["strings"] for t in e),
+            "round_trip_exact": exact,
+            "note": "entropy.custom_decompress of the batch's strings held as Python bytes (upload + both range decodes "
+                    "+ h_s + g_s), wall time of back-to-back calls; one wave per string",
+        }
+    if args.e2e and rank == 0 and coder is not None and C in (1, 3, 4):
+        # Host to host: uint8 HWC images in pinned memory -> H2D on a copy stream -> forward with the fused to_tensor
+        # ingest (dsic_conv_first_u8hwc) + metrics + coder -> strings and lengths D2H into pinned memory.
+        u8 = (x.permute(0, 2, 3, 1).clamp(0, 1) * 255.0).round().to(torch.uint8).contiguous()
+        host_in = u8.cpu().pin_memory()
+        dev_in = [torch.empty_like(u8) for _ in range(2)]
+        cap = coder.last["bytes"].shape[1]
+        host_bytes = [torch.empty((B, cap), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        host_len = [torch.empty((B, 2), dtype=torch.int32).pin_memory() for _ in range(2)]
+        ms_img = None
+
+        def e2e_step(i):
+            nonlocal ms_img
+            k = i & 1
+            # the upload runs on the main stream itself (0.23 ms for 12.6 MB): on a stream of its own it shared a hardware
+            # queue with the coder's streams and cost 1.2 ms per step
+            dev_in[k].copy_(host_in, non_blocking=True)
+            o = model(dev_in[k], quant_mode="round", after_rate=coder)
+            xf = dev_in[k].permute(0, 3, 1, 2).float() / 255.0
+            ms_img = metrics.ms_ssim_per_image(o["x_hat"], xf, clamp_x=True)
+            last = coder.last
+            # on the coder's own side stream, behind the encoder (a sixth stream for the D2H alone shared a hardware
+            # queue with the others: +3.5 ms per step)
+            with torch.cuda.stream(coder.streams[(coder.calls - 1) % len(coder.streams)]):
+                host_bytes[k].copy_(last["bytes"], non_blocking=True)
+                host_len[k].copy_(last["lengths"], non_blocking=True)
+
+        coder.reserve_events(args.steps + 4)      # (creating a HIP event inside the loop stalls the enqueue thread)
+        for i in range(3):
+            e2e_step(i)
+        torch.cuda.synchronize()
+        te = time.perf_counter()
+        for i in range(args.steps):
+            e2e_step(i)
+        coder.wait()
+        torch.cuda.synchronize()
+        ems = (time.perf_counter() - te) / args.steps * 1e3
+        e2e_stats = {
+            "ms_per_step": ems, "images_per_s": B / ems * 1e3,
+            "h2d_bytes_per_step": int(host_in.numel()), "d2h_bytes_per_step": int(B * cap + B * 8),
+            "note": "pinned uint8 HWC images -> H2D (main stream) -> dsic_conv_first_u8hwc ... coder -> worst-case string "
+                    "buffers + lengths D2H (on the coder's stream, behind the encoder) into pinned memory; copies overlap the next / previous batch",
+        }
 
     if rank == 0:
         agg = timer.summary()
@@ -339,7 +425,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
-            "vs_baseline": None,
+            "vs_baseline": None,          # BASELINE.md holds no published throughput for this metric
             "dtype": "f32 (Winograd contractions as split-bf16 MFMA with fp32 accumulate)"
                      if any("bf16" in k for k in agg) else "f32",
             "data": "synthetic",
@@ -348,7 +434,8 @@ def main():
                             "(g_a,h_a,round,h_s,Student-t/Gaussian rate,g_s) + bpp + MS-SSIM[.3,.5,.2] on GPU"
                             + (" [BASELINE config 2]" if args.no_entropy else
                                " + CDF tables and range coder (z,y strings) on GPU [BASELINE config 3]")
-                            + ("" if (H, W, C) == (256, 256, 3) else " [shape of BASELINE config 5]"),
+                            + ("" if (H, W, C) == (256, 256, 3) else " [shape of BASELINE config 5]")
+                            + (" [spatial_params=True: per-element sigma/nu and coder tables]" if spatial else ""),
                 "global_batch": B * world,
                 "parallelism": f"per-image sharding x{world}, one all-reduce of 4 fp64",
                 "weights": "synthetic seed 1 (checkpoints absent from the reference)",
@@ -358,6 +445,8 @@ def main():
             "mean_bpp_coded": (float(tot[3] / n_img) if not args.no_entropy else None),
             "images_per_s_per_gpu": value / world,
             "coder": coder_stats,
+            "decoder": decoder_stats,
+            "e2e": e2e_stats,
             "roofline": {
                 "bound": "mfma",
                 "kernel": name,
@@ -403,6 +492,7 @@ def main():
                           + f"), median; 1 thread: {v_one:.3f} images/s over {n_one} images (cpu.sbatch:5 requests 1 CPU)",
                 "value_1thread": v_one,
             }
+            res["vs_cpu_baseline"] = value / v_all        # context only: the roofline fraction is the quality measure
         print(json.dumps(res))
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

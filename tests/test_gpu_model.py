@@ -40,7 +40,7 @@ def test_forward_matches_reference_fixture(path):
     zq = out["z_tilde"].cpu().numpy()
     flips = int((yq != g["y_tilde"].astype(np.float32)).sum())
     zflips = int((zq != g["z_tilde"].astype(np.float32)).sum())
-    assert flips <= 4 and zflips <= 1, (flips, zflips)
+    assert flips <= 4 and zflips == 0, (flips, zflips)
     if spatial:   # per-element sigma/nu [B,M,H/16,W/16] (model.py:49-51)
         assert out["sigma"].shape == out["y_tilde"].shape
         np.testing.assert_allclose(out["sigma"].cpu().numpy(), g["sigma"], rtol=2e-4)
@@ -56,20 +56,28 @@ def test_forward_matches_reference_fixture(path):
     # the nll tensors carry the same sums
     s2 = out["nll_y"].double().sum(dim=(1, 2, 3)).cpu().numpy()
     assert np.max(np.abs(s2 - sums[:, 0])) < 1e-2
-    if flips == 0:
-        np.testing.assert_allclose(out["x_hat"][:, :, :32, :32].cpu().numpy(), g["x_hat_crop"], atol=1e-4)
-        xm = out["x_hat"].double().mean(dim=(1, 2, 3)).cpu().numpy()
-        assert np.max(np.abs(xm - g["x_hat_mean"])) < 1e-5
+    x_hat, g_s_taps = out["x_hat"], None
+    if flips:
+        # a flipped latent (split-bf16 default: <= 3 on two fixtures) changes everything downstream of it: synthesis
+        # parity is then asserted from the FIXTURE's latents
+        from dsic_amd import ops
+        g_s_taps = []
+        x_hat = m.g_s.forward_nhwc(ops.nchw_to_nhwc(torch.from_numpy(g["y_tilde"].astype(np.float32)).cuda()), g_s_taps)
+    np.testing.assert_allclose(x_hat[:, :, :32, :32].cpu().numpy(), g["x_hat_crop"], atol=1e-4)
+    xm = x_hat.double().mean(dim=(1, 2, 3)).cpu().numpy()
+    assert np.max(np.abs(xm - g["x_hat_mean"])) < 1e-5
     # per-layer activations at the sampled positions
     taps = dict(zip(TAP_ORDER, out.layer_taps))
     assert len(out.layer_taps) == len(TAP_ORDER)
+    if g_s_taps is not None:                           # g_s from the fixture's latents (see above)
+        gs_tags = [t for t in TAP_ORDER if t.startswith("g_s")]
+        assert len(g_s_taps) == len(gs_tags)
+        taps.update(dict(zip(gs_tags, g_s_taps)))
     for tag, a in taps.items():
         if tag == "g_s.12":
             nchw = a
         else:
             nchw = a.permute(0, 3, 1, 2)
-        if (tag.startswith("g_s") and flips) or (tag.startswith("h_s") and zflips):
-            continue                                   # downstream of a flipped latent
         assert tuple(g[f"act/{tag}/shape"]) == tuple(nchw.shape), tag
         val = nchw.reshape(-1)[torch.from_numpy(g[f"act/{tag}/idx"]).cuda()].cpu().numpy()
         scale = float(g[f"act/{tag}/absmean"][0]) + 1e-6
@@ -91,6 +99,25 @@ def test_forward_vs_oracle_live():
         assert out[k].shape == ref[k].shape
         scale = float(ref[k].abs().mean())
         assert float((out[k].cpu() - ref[k]).abs().max()) < 1e-3 * scale + 1e-5, k
+
+
+@pytest.mark.parametrize("N,M", [(72, 96), (96, 192)])
+def test_other_channel_widths(N, M):
+    """cfg.MODEL.N / M are configurable in the reference (train.py:139-143, config.py:20-28): N = 96 keeps the
+    Winograd kernels (Cin % 32 == 0), N = 72 falls back to the direct implicit GEMM for every layer it must."""
+    from dsic_amd.model import CompressionModel
+    sd = S.make_state_dict(seed=7, N=N, M=M)
+    m = CompressionModel(N=N, M=M, spatial_params=False, min_nu=2, max_nu=100.0)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    m = m.cuda().eval()
+    x = torch.from_numpy(S.make_patches(200, 2, 64, 96))
+    ref = O.forward(sd, x, "round")
+    out = m(x.cuda(), quant_mode="round")
+    assert out["y_tilde"].shape == ref["y_tilde"].shape == (2, M, 4, 6)
+    assert int((out["y_tilde"].cpu() != ref["y_tilde"]).sum()) <= 4
+    bpp = out.sums.sum(dim=1).cpu().numpy() / (64 * 96)
+    bpp_ref = (ref["nll_y"].double().sum(dim=(1, 2, 3)) + ref["nll_z"].double().sum(dim=(1, 2, 3))).numpy() / (64 * 96)
+    assert np.max(np.abs(bpp - bpp_ref)) < 1e-4
 
 
 def test_api_errors_and_modes():

@@ -13,6 +13,8 @@ are evaluated
                 products hh, hm, mh, mm, hl, lh accumulated in float32  (the candidate)
     split3    : planes hi, mid only; products hh, hm, mh                (cheaper candidate)
     bf16      : single bf16 plane                                       (what SURVEY §7 rules out)
+    f16split3 : two fp16 planes (11 bits each) per operand, the three products of split3, fp16 MFMA at the bf16
+                rate; the transformed weights scaled by a power of two per layer (f16split3_noscale: no scale)
 and compares y_tilde / z_tilde / bpp with the 9 reference fixtures tests/golden/forward_*.npz.
 bf16 x bf16 products are exact in float32, so `a.float() @ b.float()` on bf16-representable
 values reproduces an MFMA with fp32 accumulate up to the summation order.
@@ -50,8 +52,26 @@ def planes(t, n):
     return out
 
 
+def planes_f16(t, n, scale=1.0):
+    """fp16 planes (11-bit significands, round to nearest even like v_cvt_f16_f32) of t * scale; the planes are
+    returned un-scaled again (a power-of-two scale is exact).  Values below 2^-24 * scale flush to zero, subnormal
+    planes lose bits: what the scale is for."""
+    out, r = [], t * scale
+    for _ in range(n):
+        p = r.half().float()
+        out.append(p / scale)
+        r = r - p
+    return out
+
+
 def pos_gemm(V, U):
     """V [16, T, Ci] x U [16, Ci, Co] -> [16, T, Co] under MODE."""
+    if MODE in ("f16split3", "f16split3_noscale"):
+        # two fp16 planes per operand, the same three products as split3; the transformed weights are scaled by a
+        # power of two per layer so that their mid plane (2^-11 of the hi plane) stays a normal fp16 number
+        su = 1.0 if MODE.endswith("noscale") else float(2.0 ** np.floor(np.log2(256.0 / float(U.abs().max()))))
+        (vh, vm), (uh, um) = planes_f16(V, 2), planes_f16(U, 2, su)
+        return (torch.bmm(vh, um) + torch.bmm(vm, uh)) + torch.bmm(vh, uh)
     if MODE == "fp32":
         return torch.bmm(V, U)
     if MODE == "bf16":
