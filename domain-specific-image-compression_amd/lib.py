@@ -110,6 +110,17 @@ def load() -> ctypes.CDLL:
         # streams and allocations (loading /opt/rocm's copy beside it gives
         # "no ROCm-capable device").
         import torch  # noqa: F401
+        # A rank drives up to six HIP streams (main, hyperprior branch, two coder streams, RCCL, copies); on the HIP
+        # runtime's default of 4 hardware queues two of them share one and wait for each other (bench: -20 % under
+        # RCCL).  The setting is read when the runtime initialises, so it is made here, before the first HIP call of
+        # a process that has not made one yet; a process that already has is told.
+        if "GPU_MAX_HW_QUEUES" not in os.environ:
+            if torch.cuda.is_initialized():
+                import warnings
+                warnings.warn("dsic_amd: the HIP runtime was initialised without GPU_MAX_HW_QUEUES=8; the coder's side "
+                              "streams will share hardware queues with the conv stream (export it before starting python)")
+            else:
+                os.environ["GPU_MAX_HW_QUEUES"] = "8"
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
