@@ -104,7 +104,7 @@ def _cap(n):
 
 
 @torch.no_grad()
-def compress_latents(y_tilde, z_tilde, sigma_y, nu_y, sigma_z, tail=10, Lmax=DEFAULT_LMAX, streams_per_wg=4):
+def compress_latents(y_tilde, z_tilde, sigma_y, nu_y, sigma_z, tail=10, Lmax=DEFAULT_LMAX, streams_per_wg=1):
     """Device-resident compress of already computed latents.
 
     y_tilde [B,M,Hy,Wy], z_tilde [B,N,Hz,Wz] integer-valued (quant_mode="round");
@@ -167,7 +167,7 @@ class AsyncCompressor:
     coder of batch i, so a coder that takes longer than one step (512x512 patches: 196 608 y symbols
     per string, a serial chain) still keeps up - its latency is hidden, its throughput doubles."""
 
-    def __init__(self, model, tail=10, Lmax=DEFAULT_LMAX, stream=None, streams_per_wg=4, depth=1):
+    def __init__(self, model, tail=10, Lmax=DEFAULT_LMAX, stream=None, streams_per_wg=1, depth=1):
         self.model, self.tail, self.Lmax = model, tail, Lmax
         self.streams_per_wg = streams_per_wg
         self.streams = [stream if stream is not None else torch.cuda.Stream()]

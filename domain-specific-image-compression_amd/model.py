@@ -36,6 +36,9 @@ HYPER_STREAM = os.environ.get("DSIC_HYPER_STREAM", "1") != "0"
 class CompressionModel(nn.Module):
     def __init__(self, N=128, M=192, spatial_params=False, min_nu=1.1, max_nu=100.0, in_ch=3):
         super().__init__()
+        if N % 16 or M % 8 or N < 16 or M < 8:
+            raise ValueError(f"CompressionModel: N={N} must be a multiple of 16 and M={M} a multiple of 8 (NHWC tiles of the "
+                             "HIP kernels; the reference's widths 128 / 192 and every multiple of 32 run on the Winograd path)")
         self.g_a = AnalysisTransform(N, M, in_ch=in_ch)
         self.g_s = SynthesisTransform(N, M, out_ch=in_ch)
         self.h_a = HyperAnalysis(M, N)

@@ -8,6 +8,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# read by the HIP runtime when it initialises (dsic_amd.lib.load() explains): before any test touches the GPU
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def pytest_configure(config):

@@ -36,7 +36,8 @@ def test_custom_compress_is_bit_exact_to_oracle(model, B, H, W):
     y, z, sy, ny, sz = _oracle_inputs(out, model)
     want = E.compress(y, z, sy, ny, sz, tail=10)
     got = entropy.custom_compress(model, x, tail=10)
-    assert set(got) == {"strings", "shape_y", "shape_z", "min_y", "max_y", "min_z", "max_z"}
+    # the reference's keys (eval_selfcontained_entropy.py:68-74) plus the encoder's numerics tag
+    assert set(got) == {"strings", "shape_y", "shape_z", "min_y", "max_y", "min_z", "max_z", "numerics"}
     for k in ("shape_y", "shape_z", "min_y", "max_y", "min_z", "max_z"):
         assert got[k] == want[k], k
     for b in range(B):

@@ -101,10 +101,13 @@ def test_forward_vs_oracle_live():
         assert float((out[k].cpu() - ref[k]).abs().max()) < 1e-3 * scale + 1e-5, k
 
 
-@pytest.mark.parametrize("N,M", [(72, 96), (96, 192)])
+@pytest.mark.parametrize("N,M", [(80, 96), (96, 192)])
 def test_other_channel_widths(N, M):
     """cfg.MODEL.N / M are configurable in the reference (train.py:139-143, config.py:20-28): N = 96 keeps the
-    Winograd kernels (Cin % 32 == 0), N = 72 falls back to the direct implicit GEMM for every layer it must."""
+    Winograd kernels (Cin % 32 == 0), N = 80 falls back to the direct implicit GEMM for every layer it must; widths
+    that are not a multiple of 16 are refused by the constructor (the last layer's kernel needs Cin % 16 == 0)."""
+    with pytest.raises(ValueError):
+        __import__("dsic_amd.model", fromlist=["CompressionModel"]).CompressionModel(N=72, M=96)
     from dsic_amd.model import CompressionModel
     sd = S.make_state_dict(seed=7, N=N, M=M)
     m = CompressionModel(N=N, M=M, spatial_params=False, min_nu=2, max_nu=100.0)
