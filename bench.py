@@ -161,6 +161,8 @@ def main():
                     help="CUs reserved for the range coder's stream (0 = no CU masking)")
     ap.add_argument("--lanes", type=int, default=1,
                     help="batches in flight: step i runs on stream i %% lanes (kernel tails of one batch overlap the next)")
+    ap.add_argument("--no-stagger", action="store_true",
+                    help="analysis and synthesis of a batch back to back (default: the analysis runs one batch ahead)")
     ap.add_argument("--no-entropy", action="store_true",
                     help="BASELINE config 2 (transforms + rate + metrics only).  The default is config 3: the "
                          "CDF tables and the range coder of the z,y strings also run on the GPU (second stream)")
@@ -213,9 +215,41 @@ def main():
 
     pending = []
 
+    # --lanes L: step i runs on stream i % L, so the tail of one batch's kernels (workgroups of a persistent kernel
+    # finish up to one tile apart) and its small layers overlap the next batch's; every lane is joined before the
+    # clock stops
+    lanes = None
+    if args.lanes > 1:
+        lanes = [torch.cuda.Stream() for _ in range(args.lanes)]
+        for ln in lanes:
+            ln.wait_stream(torch.cuda.current_stream())
+
+    # Step order.  A step = analysis (+ hyperprior branch, rate, coder start) of one batch and synthesis (+ metrics) of one
+    # batch.  By default the analysis runs ONE BATCH AHEAD of the synthesis (A0 A1 S0 A2 S1 ... S(K-1): K analyses and K
+    # syntheses inside the timed region, every batch complete before the clock stops): the serial range coder of a batch
+    # (4.4 ms) then hides behind the syntheses of two batches instead of one, and the run no longer ends with 2.5 ms in
+    # which only the last batch's coder works.  --no-stagger runs A_i S_i back to back.
+    staged = []
+
     def step():
         # range coder of this batch runs on a second stream beside synthesis + MS-SSIM
-        out = model(x, quant_mode="round", after_rate=coder)
+        if args.no_stagger or lanes is not None:
+            out = model(x, quant_mode="round", after_rate=coder)
+            return finish(out, coder.last if coder is not None else None)
+        st = model.encode_stage(x, quant_mode="round", after_rate=coder)
+        staged.append((st, coder.last if coder is not None else None))
+        if len(staged) < 2:
+            return None
+        st, clast = staged.pop(0)
+        return finish(model.decode_stage(st), clast)
+
+    def drain():
+        # the synthesis (+ metrics) the staggered order still owes at the end
+        while staged:
+            st, clast = staged.pop(0)
+            finish(model.decode_stage(st), clast)
+
+    def finish(out, clast):
         bpp = out.sums.sum(dim=1) / float(H * W)                 # per image (modelseval.py:90-94)
         msssim = metrics.ms_ssim_per_image(out["x_hat"], x, clamp_x=True)
         real = zero
@@ -224,7 +258,7 @@ def main():
             # analysis); the coded size that enters this step's reduction is that of the step
             # `coder_depth` earlier (same batch), joined at stream level without a host sync.  The
             # last steps are joined before the clock stops.
-            pending.append(coder.last)
+            pending.append(clast)
             if len(pending) > max(1, args.coder_depth):
                 prev = pending.pop(0)
                 torch.cuda.current_stream().wait_event(prev["done"])
@@ -240,15 +274,6 @@ def main():
 
     # warm-up; its last step runs with the kernel timer on so that the event pool (and the coder's)
     # exists before the clock starts
-    # --lanes L: step i runs on stream i % L, so the tail of one batch's kernels (workgroups of a persistent kernel
-    # finish up to one tile apart) and its small layers overlap the next batch's; every lane is joined before the
-    # clock stops
-    lanes = None
-    if args.lanes > 1:
-        lanes = [torch.cuda.Stream() for _ in range(args.lanes)]
-        for ln in lanes:
-            ln.wait_stream(torch.cuda.current_stream())
-
     def run_step(i):
         if lanes is None:
             return step()
@@ -258,6 +283,7 @@ def main():
     for i in range(max(args.warmup, args.lanes if lanes else 0)):
         timer.enabled = i == max(args.warmup, args.lanes if lanes else 0) - 1
         run_step(i)
+    drain()
     timer.enabled = False
     per_step = timer.used + 1
     if not args.kernels:
@@ -272,6 +298,7 @@ def main():
     timer.reserve(per_step * args.steps + 8)
     if coder is not None:
         coder.reserve_events(args.steps + 1)
+    model.reserve_stage_events(args.steps + 2)
     timer.reset()
     barrier()
     timer.enabled = True
@@ -280,6 +307,7 @@ def main():
     for i in range(args.steps):
         marks.append(timer.mark())
         run_step(i)
+    drain()
     if lanes is not None:
         for ln in lanes:
             torch.cuda.current_stream().wait_stream(ln)

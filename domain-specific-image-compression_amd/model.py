@@ -50,6 +50,7 @@ class CompressionModel(nn.Module):
         self.spatial_params = spatial_params
         self.N, self.M = N, M
         self._fork = {}              # (device index, caller's stream) -> (side stream, fork event, join event)
+        self._stage_events = None    # pre-created join events (reserve_stage_events)
 
     def _hyper_fork(self, device, main):
         # one side stream per stream the model is called on: two batches in flight on two streams must not share
@@ -81,14 +82,19 @@ class CompressionModel(nn.Module):
         `after_rate(partial)` (optional) is called once the latents, sigma/nu and
         the rate terms are enqueued and BEFORE synthesis is launched, so a caller
         can start the range coder on a second HIP stream beside g_s."""
+        return self.decode_stage(self.encode_stage(x, quant_mode, collect_taps, after_rate, _staged=False))
+
+    @torch.no_grad()
+    def encode_stage(self, x, quant_mode="noise", collect_taps=False, after_rate=None, _staged=True):
+        """The first half of forward(): g_a, and - forked onto the side stream - h_a, round, h_s, the rate terms and the
+        `after_rate` hook (model.py:39-59).  Returns the state decode_stage() turns into forward()'s dict.  A caller that
+        streams batches may run encode_stage(i + 1) before decode_stage(i): the range coder of a batch then has the
+        synthesis of two batches to hide behind (bench.py)."""
         if quant_mode not in ("noise", "round"):
             raise ValueError(f"Unknown quant mode: {quant_mode}")
         if x.dim() != 4:
             raise ValueError(f"expected [N,C,H,W], got {tuple(x.shape)}")
-        if x.dtype == torch.uint8:
-            B, H, W, _ = x.shape
-        else:
-            B, _, H, W = x.shape
+        B = x.shape[0]
         taps = [] if collect_taps else None
         y = self.g_a.forward_from_image(x, taps)           # [B,H/16,W/16,M]
         y_noisy = self.quantize(y, "noise") if quant_mode == "noise" else None
@@ -106,21 +112,40 @@ class CompressionModel(nn.Module):
                             "sums": r["sums"]})
             return z, sigma, nu, r
 
+        joined = None
         if HYPER_STREAM:
             main = torch.cuda.current_stream(y.device)
             side, forked, joined = self._hyper_fork(y.device, main)
+            if _staged:
+                # an event of its own per call: two batches may be between their stages at the same time
+                joined = self._stage_events.pop() if self._stage_events else torch.cuda.Event()
             forked.record(main)
             with torch.cuda.stream(side):
                 side.wait_event(forked)
                 z, sigma, nu, r = hyper_branch()
                 joined.record(side)
-            x_hat = self.g_s.forward_nhwc(y_hat, taps)
-            # the branch's tensors live in the side stream's pool; every later use on `main` is ordered after
-            # this join, and the next fork waits for `main`, so the pool never recycles them under a reader
-            main.wait_event(joined)
         else:
             z, sigma, nu, r = hyper_branch()
-            x_hat = self.g_s.forward_nhwc(y_hat, taps)
+        # y_noisy rides along: the side stream reads it, so it must outlive the join in decode_stage (it was allocated on
+        # the main stream, whose pool would hand the block to g_s while the rate kernel still reads it)
+        return {"B": B, "y": y, "y_hat": y_hat, "z": z, "sigma": sigma, "nu": nu, "r": r, "taps": taps, "joined": joined,
+                "y_noisy": y_noisy}
+
+    def reserve_stage_events(self, n):
+        """create n join events now (bench.py: creating a HIP event inside a timed loop stalls the enqueue thread)"""
+        self._stage_events = [torch.cuda.Event() for _ in range(n)]
+        for e in self._stage_events:
+            e.record()
+
+    @torch.no_grad()
+    def decode_stage(self, st):
+        """The second half of forward(): g_s on round(y) (model.py:62-63), joined with the hyperprior branch."""
+        y, z, sigma, nu, r, taps, B = st["y"], st["z"], st["sigma"], st["nu"], st["r"], st["taps"], st["B"]
+        x_hat = self.g_s.forward_nhwc(st["y_hat"], taps)
+        if st["joined"] is not None:
+            # the branch's tensors live in the side stream's pool; every later use on `main` is ordered after
+            # this join, and the next fork waits for `main`, so the pool never recycles them under a reader
+            torch.cuda.current_stream(y.device).wait_event(st["joined"])
         Hy, Wy = y.shape[1], y.shape[2]
         out = ForwardOutput({
             "x_hat": x_hat,

@@ -224,3 +224,30 @@ def test_hyper_branch_on_second_stream_gives_the_same_bits():
         assert torch.equal(a.sums, b.sums)
     assert torch.equal(hooked["x_hat"], ref[0]["x_hat"]) and torch.equal(hooked.sums, ref[0].sums)
     assert strings == ref_strings
+
+
+def test_async_coder_depth_two_over_back_to_back_steps():
+    """bench.py's headline pipeline: AsyncCompressor(depth=2) with timing events, the coder of batch i running beside
+    synthesis of i and analysis of i+1 on alternating side streams.  The strings and lengths of every step equal the
+    synchronous custom_compress of the same batch, and the error flag stays clear
+    (eval_selfcontained_entropy.py:36-74)."""
+    from dsic_amd import entropy
+    m, _ = build_model(1, 3)
+    xs = [torch.from_numpy(S.make_patches(300 + 16 * i, 16, 128, 128)).cuda() for i in range(5)]
+    want = [entropy.custom_compress(m, x)["strings"] for x in xs]
+    coder = entropy.AsyncCompressor(m, depth=2)
+    coder.timing = True
+    coder.reserve_events(len(xs) + 1)
+    got = []
+    for x in xs:                                   # back to back: nothing waits for the coder inside the loop
+        m(x, quant_mode="round", after_rate=coder)
+        got.append(coder.last)
+    coder.wait()
+    torch.cuda.synchronize()
+    assert len(coder.times) == len(xs) and len({id(g["bytes"]) for g in got}) == len(xs)
+    for c, ref in zip(got, want):
+        assert int(c["err"].item()) == 0
+        lengths, raw = c["lengths"].cpu().numpy(), c["bytes"].cpu().numpy()
+        for b in range(raw.shape[0]):
+            assert raw[b, :lengths[b, 0]].tobytes() == ref[b][0], f"z string of image {b}"
+            assert raw[b, c["cap_z"]:c["cap_z"] + lengths[b, 1]].tobytes() == ref[b][1], f"y string of image {b}"
