@@ -33,7 +33,7 @@ def short(name):
         args = [a.strip() for a in m.group(1).split(",")]
         args = ["1" if a == "true" else "0" if a == "false" else a for a in args]
         return "conv_igemm_kernel<" + ",".join(args) + ">"
-    m = re.search(r"(conv_wino_bf16_kernel|conv_wino_kernel|conv_first_kernel)<([^>]*)>", name)
+    m = re.search(r"(conv_wino_bf16m_kernel|conv_wino_bf16_kernel|conv_wino_kernel|conv_first_kernel)<([^>]*)>", name)
     if m:
         arg = m.group(2).split(",")[0].strip()          # conv_first_kernel<3, false> -> <3>
         arg = {"true": "1", "false": "0"}.get(arg, arg)
