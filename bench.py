@@ -283,8 +283,8 @@ def main():
     for i in range(max(args.warmup, args.lanes if lanes else 0)):
         timer.enabled = i == max(args.warmup, args.lanes if lanes else 0) - 1
         run_step(i)
-    drain()
     timer.enabled = False
+    drain()                      # (outside the bracketed step: the dominant symbol is picked from ONE analysis + ONE synthesis)
     per_step = timer.used + 1
     if not args.kernels:
         # An event pair costs the queue ~11 us per launch (two markers the command processor serialises on):
