@@ -227,11 +227,25 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16m_kernel(const Args a) 
     static_assert(NLOAD == 6, "the vmcnt immediates above count 6 (5) loads per window");
     // this thread's 4x4 patch inside a staged window: rows 2*pty .. +3, columns 2*ptx .. +3, quad pq
     const int patch0 = ((2 * pty) * WINW + 2 * ptx) * (CK * 4) + pq * 16;
+    // a - b on a register pair: v_pk_add_f32 with the second operand negated (there is no v_pk_sub_f32, and the
+    // compiler scalarises a vector fsub into v_sub_f32).  Every VALU instruction of a helper wave is paid in MFMA
+    // time: other waves' vector instructions do not issue while an MFMA wave of the SIMD has MFMAs queued
+    // (tools/coissue3.hip), so the transform's 72 subtractions per pass are issued as 36 packed ones.
+    auto psub = [](floatx2 x, floatx2 y) {
+      floatx2 r;
+      asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+      return r;
+    };
+    auto sub4 = [&](floatx4 x, floatx4 y) {
+      const floatx2 l = psub(floatx2{x[0], x[1]}, floatx2{y[0], y[1]}), h = psub(floatx2{x[2], x[3]}, floatx2{y[2], y[3]});
+      return floatx4{l[0], l[1], h[0], h[1]};
+    };
     auto split_store = [&](floatx4 v, unsigned char* dst) {
       const unsigned h0 = cvt_pk_bf16(v[0], v[1]), h1 = cvt_pk_bf16(v[2], v[3]);
       *(uintx2*)dst = uintx2{h0, h1};
-      const float r0 = v[0] - bf16_lo(h0), r1 = v[1] - bf16_hi(h0), r2 = v[2] - bf16_lo(h1), r3 = v[3] - bf16_hi(h1);
-      *(uintx2*)(dst + PLANEB) = uintx2{cvt_pk_bf16(r0, r1), cvt_pk_bf16(r2, r3)};
+      const floatx2 r01 = psub(floatx2{v[0], v[1]}, floatx2{bf16_lo(h0), bf16_hi(h0)});
+      const floatx2 r23 = psub(floatx2{v[2], v[3]}, floatx2{bf16_lo(h1), bf16_hi(h1)});
+      *(uintx2*)(dst + PLANEB) = uintx2{cvt_pk_bf16(r01[0], r01[1]), cvt_pk_bf16(r23[0], r23[1])};
     };
     // B^T d B for the two xi rows of a pass: window buffer wbuf -> V buffer vb.  pass A: xi 1 = r1 + r2, xi 2 = r2 - r1
     // (patch rows 1, 2 only); pass B: xi 0 = r0 - r2, xi 3 = r1 - r3.  zxi / znu: the structurally zero Winograd
@@ -247,7 +261,7 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16m_kernel(const Args a) 
           const floatx4 r1 = *(const floatx4*)(src + (1 * WINW + k) * (CK * 4));
           const floatx4 r2 = *(const floatx4*)(src + (2 * WINW + k) * (CK * 4));
           xa[k] = r1 + r2;
-          xb[k] = r2 - r1;
+          xb[k] = sub4(r2, r1);
         }
       } else {
         a_live = zxi != 0u;
@@ -258,22 +272,22 @@ __global__ __launch_bounds__(THREADS) void conv_wino_bf16m_kernel(const Args a) 
           const floatx4 r1 = *(const floatx4*)(src + (1 * WINW + k) * (CK * 4));
           const floatx4 r2 = *(const floatx4*)(src + (2 * WINW + k) * (CK * 4));
           const floatx4 r3 = *(const floatx4*)(src + (3 * WINW + k) * (CK * 4));
-          xa[k] = r0 - r2;
-          xb[k] = r1 - r3;
+          xa[k] = sub4(r0, r2);
+          xb[k] = sub4(r1, r3);
         }
       }
       // columns: nu 0: x0-x2, 1: x1+x2, 2: x2-x1, 3: x1-x3
       if (a_live) {
-        if (znu != 0) split_store(xa[0] - xa[2], dst + 0 * POSB);
+        if (znu != 0) split_store(sub4(xa[0], xa[2]), dst + 0 * POSB);
         split_store(xa[1] + xa[2], dst + 1 * POSB);
-        split_store(xa[2] - xa[1], dst + 2 * POSB);
-        if (znu != 3) split_store(xa[1] - xa[3], dst + 3 * POSB);
+        split_store(sub4(xa[2], xa[1]), dst + 2 * POSB);
+        if (znu != 3) split_store(sub4(xa[1], xa[3]), dst + 3 * POSB);
       }
       if (b_live) {
-        if (znu != 0) split_store(xb[0] - xb[2], dst + 4 * POSB);
+        if (znu != 0) split_store(sub4(xb[0], xb[2]), dst + 4 * POSB);
         split_store(xb[1] + xb[2], dst + 5 * POSB);
-        split_store(xb[2] - xb[1], dst + 6 * POSB);
-        if (znu != 3) split_store(xb[1] - xb[3], dst + 7 * POSB);
+        split_store(sub4(xb[2], xb[1]), dst + 6 * POSB);
+        if (znu != 3) split_store(sub4(xb[1], xb[3]), dst + 7 * POSB);
       }
     };
     auto zero_of = [&](const Tile& t, int k, unsigned& zxi, unsigned& znu) {

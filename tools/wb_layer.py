@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs one Winograd layer (split-bf16 or fp32 kernel) a few times, for rocprofv3 counter passes.
-LAYER=3x3 | s2 | convT ; KERNEL=bf16 | fp32 ; B, HW from the environment (defaults: bench shape of the largest layer)."""
+LAYER=3x3 | s2 | convT | image (the last layer, convT_image.hip) ; KERNEL=bf16 | fp32 ; B, HW from the environment (defaults: bench shape of the largest layer)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,6 +13,11 @@ if layer == "s2":
     w = ops.pack_wino_s2_weight(torch.randn(128, 128, 5, 5, device="cuda") * 0.05)
     if kern == "bf16": w = ops.split_wino_weight_bf16(w, 128, 512)
     run = lambda: ops.conv3x3_wino_nhwc(x, w, bias, 128, ops.ACT_GDN, beta, gamma, s2d_in=True)
+elif layer == "image":
+    x = torch.randn(B, h, h, 128, device="cuda")
+    wp = ops.pack_convT_image_weight(torch.randn(128, 3, 5, 5, device="cuda") * 0.05)
+    b3 = torch.randn(3, device="cuda")
+    run = lambda: ops.conv_transpose2d_image(x, wp, b3, 3)
 elif layer == "convT":
     x = torch.randn(B, h // 2, h // 2, 128, device="cuda")
     w = ops.pack_wino_convT_weight(torch.randn(128, 128, 5, 5, device="cuda") * 0.05)
