@@ -41,7 +41,11 @@ __device__ __forceinline__ void img_split(floatx4 v, uintx2& hi, uintx2& mid) {
   mid = __builtin_bit_cast(uintx2, __builtin_convertvector(r, bf16x4));
 }
 
-constexpr int IT_W = 32, IT_H = 16;          // input-grid pixels per workgroup tile
+#ifndef IMG_TH
+#define IMG_TH 16
+#endif
+constexpr int IT_W = 32, IT_H = IMG_TH;      // input-grid pixels per workgroup tile
+constexpr int RPW = IT_H / 4, NM = 2 * RPW;  // tile rows and M tiles (16 pixels) per wave
 constexpr int IW = IT_W + 2, IH = IT_H + 2;  // staged window
 constexpr int ICK = 16, IP = ICK + 4;        // channels per chunk, LDS floats per window pixel
 constexpr int ISLOTS = (IH * IW * (ICK / 4) + 255) / 256;  // float4 staging slots per thread
@@ -142,11 +146,11 @@ __global__ __launch_bounds__(256, IMG_WGS) void convT_image_kernel(const ImgArgs
       }
   };
 
-  floatx4 acc[8];
+  floatx4 acc[NM];
 #pragma unroll
-  for (int m = 0; m < 8; ++m) acc[m] = floatx4{0.f, 0.f, 0.f, 0.f};
+  for (int m = 0; m < NM; ++m) acc[m] = floatx4{0.f, 0.f, 0.f, 0.f};
   // A fragment of M tile m (row m>>1 of this wave, x half m&1) at tap (0,0): + (wr*IW + wc)*IP per tap
-  const int abase = ((wave * 4) * IW + r) * IP + 4 * q;
+  const int abase = ((wave * RPW) * IW + r) * IP + 4 * q;
   const float* wl = a.w + r * 16 + 4 * q;  // + (tap*C16 + chunk)*256
   // bf16 planes of the weights: [chunk][tap][plane][half][col 16][8 channels] behind the 9 Cin 16 fp32 values.  A
   // chunk's 9 KB go global -> LDS by buffer_load_dwordx4 ... lds (wave w: the 1 KB blocks of taps w, w + 4, w + 8;
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256, IMG_WGS) void convT_image_kernel(const ImgArgs
       // lane (col r, q) takes half q & 1 of plane hi (B1) and of plane mid (B2)
       const unsigned char* wc0 = wlds + (chunk & 1) * IMG_WCH + ((q & 1) * 16 + r) * 16;
       // A fragment of lane (r, q): bytes 16 q .. of the record of pixel r of the M tile
-      const unsigned char* abyte = (const unsigned char*)lds + (size_t)((wave * 4) * IW + r) * (IP * 4) + q * 16;
+      const unsigned char* abyte = (const unsigned char*)lds + (size_t)((wave * RPW) * IW + r) * (IP * 4) + q * 16;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int wr = tap / 3, wc = tap % 3;
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(256, IMG_WGS) void convT_image_kernel(const ImgArgs
         if (IMG_ABL & 4) { B1 = bf16x8{1, 2, 3, 4, 5, 6, 7, 8}; B2 = B1; }
         else { B1 = *(const bf16x8*)(wc0 + tap * 1024); B2 = *(const bf16x8*)(wc0 + tap * 1024 + 512); }
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
+        for (int m = 0; m < NM; ++m) {
           const unsigned char* ap = abyte + (size_t)((((m >> 1) + wr) * IW + (m & 1) * 16 + wc) * (IP * 4));
           bf16x8 A;
           if (IMG_ABL & 32) A = B1;
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(256, IMG_WGS) void convT_image_kernel(const ImgArgs
         const floatx4 bc = b;
         if (tap + 1 < 9) b = *(const floatx4*)(wl + (size_t)((tap + 1) * C16 + chunk) * 256);
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
+        for (int m = 0; m < NM; ++m) {
           const floatx4 av = *(const floatx4*)(lds + abase + (((m >> 1) + wr) * IW + (m & 1) * 16 + wc) * IP);
 #pragma unroll
           for (int s = 0; s < 4; ++s) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bc[s], acc[m], 0, 0, 0);
@@ -232,8 +236,8 @@ __global__ __launch_bounds__(256, IMG_WGS) void convT_image_kernel(const ImgArgs
     const float bias = a.bias[c];
     const int py = phase >> 1, px = phase & 1;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const int yl = wave * 4 + (m >> 1);
+    for (int m = 0; m < NM; ++m) {
+      const int yl = wave * RPW + (m >> 1);
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int xl = (m & 1) * 16 + 4 * q + v;

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void hyper_params_kernel(
 #define PI_D 3.141592653589793
 
 #define RATE_SPLIT 16  // workgroups per image
+#define RATE_PT 16     // pixels per LDS tile
 
 __global__ __launch_bounds__(256) void rate_kernel(
     const float* __restrict__ y, const float* __restrict__ z, const float* __restrict__ y_noisy,
@@ -99,14 +100,20 @@ __global__ __launch_bounds__(256) void rate_kernel(
     const float* __restrict__ z_log_sigma, float* __restrict__ y_hat, float* __restrict__ y_tilde,
     float* __restrict__ z_tilde, float* __restrict__ nll_y, float* __restrict__ nll_z,
     double* __restrict__ part, int HWy, int M, int HWz, int N, int per_element) {
-  // grid (RATE_SPLIT, B): block (s, b) takes the s-th slice of image b's y elements; the last slice
-  // also takes z.  part[b][s][2] = this block's {sum nll_y, sum nll_z}; rate_reduce_kernel adds the
-  // slices in fixed order (deterministic, independent of the batch).
+  // grid (RATE_SPLIT, B): block (s, b) takes the s-th range of image b's y pixels (a multiple of 4 pixels, all
+  // channels); the last one also takes z.  part[b][s][2] = this block's {sum nll_y, sum nll_z};
+  // rate_reduce_kernel adds the slices in fixed order (deterministic, independent of the batch).
+  // The NCHW outputs (y_tilde, nll_y) leave through an LDS tile of RATE_PT pixels x M channels: 16-byte stores of
+  // 4 consecutive pixels of a channel instead of 4-byte stores 4 HWy bytes apart (165 MB written per launch for
+  // 38 MB of output in round 2).
   __shared__ float s_sig[MAXM], s_nu[MAXM], s_logc[MAXM];
   __shared__ double scratch[4];
+  extern __shared__ __attribute__((aligned(16))) float rate_tile[];   // [2][M][RATE_PT + 1]
+  float* const t_x = rate_tile;
+  float* const t_b = rate_tile + (size_t)M * (RATE_PT + 1);
   const int b = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x;
-  const int per = ((HWy * M + RATE_SPLIT - 1) / RATE_SPLIT + 255) / 256 * 256;  // slice length, multiple of 256
-  const int i0 = slice * per, i1 = min(HWy * M, i0 + per);
+  const int pps = ((HWy + RATE_SPLIT - 1) / RATE_SPLIT + 3) & ~3;   // pixels per slice
+  const int p_begin = min(HWy, slice * pps), p_end = min(HWy, p_begin + pps);
   for (int c = tid; c < M && !per_element; c += 256) {
     // distributions.py:25-29; the channel constant is evaluated in fp64 and
     // rounded once (the reference evaluates it in fp32 per element).
@@ -121,32 +128,56 @@ __global__ __launch_bounds__(256) void rate_kernel(
   __syncthreads();
   double acc = 0.0;
   const size_t ybase = (size_t)b * HWy * M;
-  for (int i = i0 + tid; i < i1; i += 256) {  // i walks NHWC (coalesced reads)
-    const int p = i / M, c = i % M;
-    const float v = y[ybase + i];
-    const float r = rintf(v);  // torch.round: half to even
-    const float xt = y_noisy ? y_noisy[ybase + i] : r;
-    float sg, nv, lc;
-    if (per_element) {  // spatial_params (model.py:49-51): sigma, nu are NCHW [B,M,HWy]
-      const size_t e = ((size_t)b * M + c) * HWy + p;
-      sg = fminf(fmaxf(sigma[e], 1e-3f), 1e3f);
-      nv = fminf(fmaxf(nu[e], 2.0f), 100.0f);
-      const double nd = (double)nv;
-      lc = (float)(lgamma((nd + 1.0) * 0.5) - lgamma(nd * 0.5) - 0.5 * log(nd * PI_D) - log((double)sg));
-    } else {
-      sg = s_sig[c];
-      nv = s_nu[c];
-      lc = s_logc[c];
+  const bool vec = (HWy & 3) == 0;
+  for (int p0 = p_begin; p0 < p_end; p0 += RATE_PT) {
+    const int npx = min(RATE_PT, p_end - p0);
+    for (int i = tid; i < npx * M; i += 256) {  // i walks NHWC (coalesced reads)
+      const int pl = i / M, c = i - pl * M;
+      const int p = p0 + pl;
+      const size_t g = ybase + (size_t)p * M + c;
+      const float v = y[g];
+      const float r = rintf(v);  // torch.round: half to even
+      const float xt = y_noisy ? y_noisy[g] : r;
+      float sg, nv, lc;
+      if (per_element) {  // spatial_params (model.py:49-51): sigma, nu are NCHW [B,M,HWy]
+        const size_t e = ((size_t)b * M + c) * HWy + p;
+        sg = fminf(fmaxf(sigma[e], 1e-3f), 1e3f);
+        nv = fminf(fmaxf(nu[e], 2.0f), 100.0f);
+        const double nd = (double)nv;
+        lc = (float)(lgamma((nd + 1.0) * 0.5) - lgamma(nd * 0.5) - 0.5 * log(nd * PI_D) - log((double)sg));
+      } else {
+        sg = s_sig[c];
+        nv = s_nu[c];
+        lc = s_logc[c];
+      }
+      const float q = xt / sg;
+      const float quad = q * q;
+      const float logp = lc - ((nv + 1.0f) / 2.0f) * log1pf(quad / nv);
+      const float bits = -logp * LOG2E_F;
+      y_hat[g] = r;
+      t_x[c * (RATE_PT + 1) + pl] = xt;
+      t_b[c * (RATE_PT + 1) + pl] = bits;
+      acc += (double)bits;
     }
-    const float q = xt / sg;
-    const float quad = q * q;
-    const float logp = lc - ((nv + 1.0f) / 2.0f) * log1pf(quad / nv);
-    const float bits = -logp * LOG2E_F;
-    y_hat[ybase + i] = r;
-    const size_t o = ((size_t)b * M + c) * HWy + p;
-    y_tilde[o] = xt;
-    nll_y[o] = bits;
-    acc += (double)bits;
+    __syncthreads();
+    for (int i = tid; i < M * (RATE_PT / 4); i += 256) {
+      const int c = i / (RATE_PT / 4), g4 = i - c * (RATE_PT / 4);
+      const int pl = 4 * g4;
+      if (pl >= npx) continue;
+      const float* tx = t_x + c * (RATE_PT + 1) + pl;
+      const float* tb = t_b + c * (RATE_PT + 1) + pl;
+      const size_t o = ((size_t)b * M + c) * HWy + p0 + pl;
+      if (vec && pl + 3 < npx) {
+        *(float4*)(y_tilde + o) = make_float4(tx[0], tx[1], tx[2], tx[3]);
+        *(float4*)(nll_y + o) = make_float4(tb[0], tb[1], tb[2], tb[3]);
+      } else {
+        for (int e = 0; e < 4 && pl + e < npx; ++e) {
+          y_tilde[o + e] = tx[e];
+          nll_y[o + e] = tb[e];
+        }
+      }
+    }
+    __syncthreads();
   }
   const double sy = block_sum(acc, scratch);
   acc = 0.0;
@@ -310,7 +341,22 @@ extern "C" int dsic_rate(const float* y_nhwc, const float* z_nhwc, const float* 
   DSIC_REQUIRE(M > 0 && M <= MAXM && N > 0, "rate: M=%d must be in [1,%d]", M, MAXM);
   DSIC_REQUIRE((int64_t)HWy * M < ((int64_t)1 << 31), "rate: latent too large");
   DSIC_REQUIRE(B <= 65535, "rate: B=%d exceeds the grid limit", B);
-  hipLaunchKernelGGL(rate_kernel, dim3(RATE_SPLIT, B), dim3(256), 0, (hipStream_t)stream, y_nhwc, z_nhwc,
+  const size_t tile_bytes = (size_t)2 * M * (RATE_PT + 1) * sizeof(float);   // <= 69 632 (M = 512)
+  if (tile_bytes > 40000) {   // beside the 6 KB of static LDS: ask for more than the default 64 KB
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    static bool attr_set[64] = {};
+    if (!attr_set[dev]) {
+      const hipError_t e = hipFuncSetAttribute((const void*)rate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               2 * MAXM * (RATE_PT + 1) * (int)sizeof(float));
+      if (e != hipSuccess) {
+        set_error("rate: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return DSIC_EHIP;
+      }
+      attr_set[dev] = true;
+    }
+  }
+  hipLaunchKernelGGL(rate_kernel, dim3(RATE_SPLIT, B), dim3(256), tile_bytes, (hipStream_t)stream, y_nhwc, z_nhwc,
                      y_noisy_nhwc, z_noisy_nhwc, sigma, nu, z_log_sigma, y_hat_nhwc, y_tilde_nchw,
                      z_tilde_nchw, nll_y_nchw, nll_z_nchw, work, HWy, M, HWz, N, per_element ? 1 : 0);
   int rc = check_launch("rate");
