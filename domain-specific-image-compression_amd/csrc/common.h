@@ -9,6 +9,7 @@
 namespace dsic {
 
 void set_error(const char* fmt, ...);
+int split_bf16();   // dsic_split_bf16(): 1 = split-bf16 contractions (default), 0 = fp32-input MFMAs
 
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();

@@ -337,13 +337,9 @@ extern "C" int dsic_conv_transpose2d_image(const float* in, const float* w_packe
   a.tiles_x = ceil_div(W, IT_W); a.tiles_y = ceil_div(H, IT_H);
   const int64_t nblk = (int64_t)a.tiles_x * a.tiles_y * B;
   DSIC_REQUIRE(nblk < ((int64_t)1 << 31), "convT_image: grid too large");
-  // DSIC_WINO_BF16=0 (the switch of the split-bf16 contractions, see conv_wino_bf16.hip) keeps this layer on
-  // the fp32-input MFMA as well
-  static int use_bf16 = -1;
-  if (use_bf16 < 0) {
-    const char* e = getenv("DSIC_WINO_BF16");
-    use_bf16 = (e && e[0] == '0' && e[1] == 0) ? 0 : 1;
-  }
+  // dsic_set_split_bf16(0) / DSIC_WINO_BF16=0 (the switch of the split-bf16 contractions, see conv_wino_bf16.hip)
+  // keeps this layer on the fp32-input MFMA as well
+  const int use_bf16 = split_bf16();
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   static bool attr_set[64] = {};

@@ -268,12 +268,9 @@ static int conv_first_launch(const void* x, bool u8, const float* w_oihw, const 
   DSIC_REQUIRE((int64_t)tx * ty * B < ((int64_t)1 << 31), "conv_first: grid too large");
   dim3 grid(tx * ty * B), block(256);
   hipStream_t st = (hipStream_t)stream;
-  // DSIC_WINO_BF16=0 (the switch that selects the exact-fp32 Winograd kernels) keeps this layer on the fp32-input MFMA
-  static int use_bf16 = -1;
-  if (use_bf16 < 0) {
-    const char* e = getenv("DSIC_WINO_BF16");
-    use_bf16 = (e && e[0] == '0' && e[1] == 0) ? 0 : 1;
-  }
+  // dsic_set_split_bf16(0) / DSIC_WINO_BF16=0 (the switch that selects the exact-fp32 Winograd kernels) keeps this
+  // layer on the fp32-input MFMA
+  const int use_bf16 = split_bf16();
 #define DSIC_FIRST(CC, UU, BB)                                                                                        \
   hipLaunchKernelGGL((conv_first_kernel<CC, UU, BB>), grid, block, 0, st, x, w_oihw, bias, beta, gamma, out_nhwc, B, H, \
                      W, Cout, act, tx, ty, s2d)

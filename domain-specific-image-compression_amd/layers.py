@@ -20,9 +20,27 @@ from . import ops
 
 # DSIC_WINOGRAD=0 forces the direct implicit-GEMM kernel for every layer (A/B runs)
 USE_WINOGRAD = os.environ.get("DSIC_WINOGRAD", "1") != "0"
-# Winograd position GEMMs on the bf16 MFMA path with operands split into bf16 planes (fp32-class
-# results, csrc/conv_wino_bf16.hip); DSIC_WINO_BF16=0 selects the fp32-input MFMA kernel.
-WINO_BF16 = os.environ.get("DSIC_WINO_BF16", "1") != "0"
+
+
+def wino_bf16() -> bool:
+    """The library's arithmetic variant (dsic_split_bf16): True = every contraction on bf16 MFMAs with operands split
+    into two bf16 planes (fp32-class results, csrc/conv_wino_bf16.hip; the default), False = fp32-input MFMAs.  One
+    switch for the first layer, the Winograd layers and the image layer; DSIC_WINO_BF16=0 only sets its initial value."""
+    from . import lib as _lib
+    return bool(_lib.load().dsic_split_bf16())
+
+
+def set_wino_bf16(on: bool) -> None:
+    """Switches the variant at run time.  Packed weights are cached per variant (_ConvBase._key), so layers built
+    before the switch follow it on their next call."""
+    from . import lib as _lib
+    _lib.check(_lib.load().dsic_set_split_bf16(1 if on else 0), "set_split_bf16")
+
+
+def __getattr__(name):   # layers.WINO_BF16: the current variant (read-only view of the switch)
+    if name == "WINO_BF16":
+        return wino_bf16()
+    raise AttributeError(name)
 
 
 class _GammaConv(nn.Module):
@@ -76,7 +94,7 @@ class _ConvBase(nn.Module):
 
     def _key(self):
         w = self.weight
-        return (w._version, w.data_ptr(), str(w.device))
+        return (w._version, w.data_ptr(), str(w.device), wino_bf16())
 
     def packed(self):
         key = self._key()
@@ -126,7 +144,7 @@ class Conv2d(_ConvBase):
             return False
         # wider outputs (g_a.14: 128 -> 192, layers.py:72) run as channel slices of <= 128 into one tensor;
         # only the split-bf16 kernel can store a slice
-        return self.out_channels <= 128 or (WINO_BF16 and self.out_channels <= 256 and 4 * self.in_channels >= 64)
+        return self.out_channels <= 128 or (wino_bf16() and self.out_channels <= 256 and 4 * self.in_channels >= 64)
 
     def _cout_slices(self):
         """(lo, hi) output-channel slices of at most 128 (multiples of 32 except the last)."""
@@ -151,7 +169,7 @@ class Conv2d(_ConvBase):
             self._wino = (ops.pack_wino_s2_weight(self.weight) if self.kernel_size == 5
                           else ops.pack_wino_weight(self.weight))
             cin = self.in_channels * (4 if self.kernel_size == 5 else 1)
-            if WINO_BF16 and cin >= 64:
+            if wino_bf16() and cin >= 64:
                 self._wino = ops.split_wino_weight_bf16(self._wino, self.out_channels, cin, 1)
             self._wino_key = key
         return self._wino
@@ -225,7 +243,7 @@ class ConvTranspose2d(_ConvBase):
             return ops.pack_convT_image_weight(self.weight)
         if self.use_winograd:
             u = ops.pack_wino_convT_weight(self.weight)
-            if WINO_BF16 and self.in_channels >= 64:
+            if wino_bf16() and self.in_channels >= 64:
                 u = ops.split_wino_weight_bf16(u, self.out_channels, self.in_channels, 4)
             return u
         return ops.pack_convT_weight(self.weight)

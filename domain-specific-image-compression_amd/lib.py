@@ -21,6 +21,8 @@ _P = c_void_p
 SIGNATURES = {
     "dsic_last_error": (ctypes.c_char_p, []),
     "dsic_abi_version": (c_int, []),
+    "dsic_split_bf16": (c_int, []),
+    "dsic_set_split_bf16": (c_int, [c_int]),
     "dsic_packed_conv_weight_floats": (c_int64, [c_int, c_int, c_int]),
     "dsic_pack_conv_weight": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "dsic_pack_convT_weight": (c_int, [_P, _P, c_int, c_int, _P]),

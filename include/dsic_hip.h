@@ -40,6 +40,14 @@ extern "C" {
 const char* dsic_last_error(void);
 int dsic_abi_version(void);
 
+/* The arithmetic variant of every contraction of the library, one run-time switch (the reference has no such
+ * notion: it is torch's fp32 conv, model.py:27-35; both variants are held to its outputs):
+ * 1 = operands split into two bf16 planes, bf16 MFMAs, fp32 accumulation (default); 0 = fp32-input MFMAs.
+ * The environment variable DSIC_WINO_BF16=0 sets the initial value to 0.  Weights packed for one variant must be
+ * re-packed after a switch (the Python layers key their caches on it). */
+int dsic_split_bf16(void);
+int dsic_set_split_bf16(int on);
+
 /* ---- weight re-layout (once per checkpoint load) ------------------------ */
 
 /* nn.Conv2d weight [Cout,Cin,k,k] (layers.py:29-31) -> packed

@@ -432,3 +432,32 @@ def test_winograd_split_k_equals_unsplit_sums(ops, B, Cin, Cout, H, W, act, s2d_
     OPS.WINO_SPLITK = True
     solo = ops.conv3x3_wino_nhwc(x[B - 1:].contiguous(), u, b, Cout, code, beta, gamma, s2d_in=s2d_in, s2d_out=s2d_out)
     assert torch.equal(solo[0], got[B - 1])
+
+
+def test_variant_switch_is_one_run_time_call(ops):
+    """dsic_set_split_bf16 (layers.set_wino_bf16): ONE switch through the C ABI moves the first layer, the Winograd
+    layers and the image layer between the split-bf16 and the fp32-input MFMA kernels; layers built before the switch
+    follow it (their packed weights are cached per variant)."""
+    from dsic_amd import layers as Lm, lib
+    L = lib.load()
+    before = Lm.wino_bf16()
+    torch.manual_seed(5)
+    g_a = Lm.AnalysisTransform(128, 192, 3).cuda()
+    g_s = Lm.SynthesisTransform(128, 192, 3).cuda()
+    x = torch.rand(2, 3, 64, 64, device="cuda")
+    try:
+        outs = {}
+        for variant in (True, False, True):
+            Lm.set_wino_bf16(variant)
+            assert bool(L.dsic_split_bf16()) == variant and Lm.WINO_BF16 == variant
+            y = g_a(x)
+            xh = g_s(torch.round(y))
+            outs.setdefault(variant, []).append((y.clone(), xh.clone()))
+        (y1, x1), (y1b, x1b) = outs[True]
+        (y0, x0), = outs[False]
+        assert torch.equal(y1, y1b) and torch.equal(x1, x1b)          # back on the first variant: the same bits
+        assert not torch.equal(y1, y0) and not torch.equal(x1, x0)    # the switch reached the kernels
+        scale = float(y0.abs().max())
+        assert float((y1 - y0).abs().max()) <= 2e-4 * scale           # two fp32-class evaluations of the same transform
+    finally:
+        Lm.set_wino_bf16(before)

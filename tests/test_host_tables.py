@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(L):
     assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.dsic_abi_version() == 3
+    assert L.dsic_abi_version() == 4
 
 
 def test_argument_validation_without_gpu(L):
