@@ -517,14 +517,14 @@ __global__ __launch_bounds__(256) void range_decode_kernel(const uint8_t* __rest
   const int nseg = (L + 63) >> 6;  // table entries per row, 64 per register
   if (nseg == 1 && !per_element) {
     // ---- fast path: the whole table row in one register, rows per channel ---------------------------------
-    // Same arithmetic, shorter chain (round 3: 371 -> 205 ns per symbol at the bench shape): the state is (low, span) with span =
+    // Same arithmetic, shorter chain (round 3: 371 -> 188 ns per symbol at the bench shape): the state is (low, span) with span =
     // high - low + 1 kept mod 2^32 (0 means 2^32) and the lanes hold c << 16, so floor(span c / 2^16) is ONE
     // v_mul_hi_u32 per lane for the search and one s_mul_hi_u32 for each bound of the decoded symbol (the general
     // path multiplies in 64 bits); c_high = 65536 (last symbol) is hi_add = span.  The two renormalisation shifts
     // (E1/E2 by nb, E3 by m) are applied together and their stream bits taken together when nb + m < 32.  Decoded
     // symbols collect in a register (lane g & 63) and leave as one coalesced 256-byte store per 64 symbols
     // instead of a 4-byte store per symbol.  (Stream bits cut out of two window lanes by absolute bit position,
-    // without the 64-bit buffer: 229 instead of 205 ns per symbol - two more v_readlane with an SGPR lane select.)
+    // without the 64-bit buffer: +24 ns per symbol - two more v_readlane with an SGPR lane select.)
     const uint64_t valid = L >= 64 ? ~0ull : ((1ull << L) - 1ull);
     auto load_row16 = [&](int64_t rw) -> uint32_t {
       return lane < L ? ((uint32_t)gt[(size_t)rw * Lmax + lane]) << 16 : 0u;
@@ -538,10 +538,9 @@ __global__ __launch_bounds__(256) void range_decode_kernel(const uint8_t* __rest
       const uint32_t d = value - low;
       const uint32_t bound = span ? __umulhi(span, ck16) : ck16;
       const int hits = __popcll(__ballot(bound <= d) & valid);   // >= 1: c[0] = 0
-      const uint32_t cl = __builtin_amdgcn_readlane(ck16, hits - 1);
-      const uint32_t ch = __builtin_amdgcn_readlane(ck16, hits & 63);
-      const uint32_t lo_add = span ? __umulhi(span, cl) : cl;
-      const uint32_t hi_mul = span ? __umulhi(span, ch) : ch;
+      // the decoded symbol's own bounds are two of the products the lanes just formed
+      const uint32_t lo_add = __builtin_amdgcn_readlane(bound, hits - 1);
+      const uint32_t hi_mul = __builtin_amdgcn_readlane(bound, hits & 63);
       const uint32_t hi_add = hits == L ? span : hi_mul;          // c_high = 65536: floor(span 2^16 / 2^16)
       {  // symbol g -> lane g & 63 of outv
         const int sv = hits - 1 + smin;
