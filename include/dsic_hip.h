@@ -65,7 +65,9 @@ int dsic_pack_convT_weight(const float* w_iohw, float* dst, int Cin, int Cout,
 
 /* Last synthesis layer ConvTranspose2d(Cin,Cimg,5,2,2,1) (layers.py:97):
  * the four phases become the 4*Cimg <= 16 output columns of ONE 3x3 stride-1
- * contraction over the input grid; packed [9][Cin/16][16][16] =
+ * contraction over the input grid; packed [9][Cin/16][16][16] fp32, followed
+ * by the same values as two bf16 planes [Cin/16][9][hi,mid][half][16][8]
+ * (the B operands of the split-bf16 kernel) = together
  * dsic_convT_image_weight_floats(Cin) floats.  Cin % 16 == 0, Cimg in [1,4]. */
 int64_t dsic_convT_image_weight_floats(int Cin);
 int dsic_pack_convT_image_weight(const float* w_iohw, float* dst, int Cin,
