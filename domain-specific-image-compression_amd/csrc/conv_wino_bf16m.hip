@@ -734,9 +734,12 @@ int dsic_wbm_launch(wb::Args& a, hipStream_t st) {
     attr_set[dev] = true;
   }
   static int max_grid_dev[64] = {};
-  if (max_grid_dev[dev] == 0) {
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+  if (max_grid_dev[dev] == 0) {   // one persistent workgroup per compute unit (DSIC_WINO_GRID: experiments)
+    const char* g = getenv("DSIC_WINO_GRID");
+    int n = g ? atoi(g) : 0;
+    if (n < 1 || n > 1024) {
+      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    }
     max_grid_dev[dev] = n;
   }
   const int grid = nt < max_grid_dev[dev] ? (int)nt : max_grid_dev[dev];
