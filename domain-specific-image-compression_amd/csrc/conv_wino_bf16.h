@@ -120,10 +120,11 @@ __device__ __forceinline__ floatx16 sub16(floatx16 a, floatx16 b) {
 }
 
 // two floats -> packed bf16 pair (round to nearest even), and the pair back as two floats
+typedef __bf16 wb_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
+  // the compiler's own v_cvt_pk_bf16_f32 (it schedules around an instruction it knows; behind inline asm it pads
+  // every use with s_nop, and a helper wave's instruction slots are MFMA time)
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(floatx2{a, b}, wb_bf16x2));
 }
 __device__ __forceinline__ float bf16_lo(unsigned pk) { return __builtin_bit_cast(float, pk << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned pk) { return __builtin_bit_cast(float, pk & 0xFFFF0000u); }
